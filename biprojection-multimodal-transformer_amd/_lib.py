@@ -1,0 +1,121 @@
+"""Build + load libbpmult_hip.so (the C ABI in include/bpmult_hip.h) and bind it
+with ctypes.  There is deliberately NO fallback: if the library is missing or a
+symbol does not resolve, importing the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libbpmult_hip.so")
+SOURCES = ("gemm.hip", "attention.hip", "rowops.hip")
+ARCH = "gfx950"
+
+BPM_F32, BPM_BF16 = 0, 1
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
+F_ACCUM, F_RELU, F_ATOMIC = 1, 2, 4
+LN_OUT_F32 = 2
+MAX_GROUP = 12
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every csrc/*.hip into one shared library (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "bpm_common.h"), os.path.join(_HERE, "..", "include", "bpmult_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+                ("bias_n", C.c_void_p), ("bias_m", C.c_void_p),
+                ("resid", C.c_void_p), ("ldr", C.c_int),
+                ("gate", C.c_void_p), ("ldg", C.c_int), ("gate_scale", C.c_float),
+                ("alpha", C.c_float), ("drop_p", C.c_float),
+                ("drop_seed", C.c_uint64), ("drop_site", C.c_uint32),
+                ("flags", C.c_int), ("out_kind", C.c_int), ("splitk", C.c_int),
+                ("heads_B", C.c_int), ("heads_H", C.c_int), ("heads_T", C.c_int),
+                ("heads_dh", C.c_int), ("heads_dhp", C.c_int)]
+
+
+class AttnProblem(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p),
+                ("O", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
+                ("dO", C.c_void_p), ("delta", C.c_void_p),
+                ("dQ", C.c_void_p), ("lddq", C.c_int),
+                ("dK", C.c_void_p), ("lddk", C.c_int),
+                ("dV", C.c_void_p), ("lddv", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("S", C.c_int),
+                ("dh", C.c_int), ("dhp", C.c_int), ("mask_off", C.c_int),
+                ("dq_scale", C.c_float), ("drop_p", C.c_float),
+                ("drop_seed", C.c_uint64), ("drop_site", C.c_uint32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
+                ("ld", C.c_int), ("blk0", C.c_uint)]
+
+
+_P, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
+
+# every symbol include/bpmult_hip.h declares: name -> argtypes
+SIGNATURES = {
+    "bpm_version": [],
+    "bpm_error_string": [_I],
+    "bpm_gemm_grouped": [_I, _I, C.POINTER(GemmProblem), _I, _P],
+    "bpm_attn_fwd": [_I, C.POINTER(AttnProblem), _I, _P],
+    "bpm_attn_bwd": [_I, C.POINTER(AttnProblem), _I, _P],
+    "bpm_pack_rows_fwd": [_I, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _P],
+    "bpm_pack_rows_bwd": [_P, _I, _P, _I, _I, _I, _F, _U64, _U32, _P],
+    "bpm_pack_weights": [_I, _P, _I, C.c_uint, _P],
+    "bpm_embed_pos_fwd": [_P, _P, _I, _P, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    "bpm_embed_pos_bwd": [_P, _P, _I, _I, _I, _F, _F, _U64, _U32, _I, _P],
+    "bpm_ln_fwd": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
+    "bpm_ln_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "bpm_rows_cast": [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _U32, _P],
+    "bpm_gmu2_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "bpm_gmu2_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The BPMulT hot path has no CPU/PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)            # AttributeError if the symbol is missing
+            fn.argtypes = args
+            fn.restype = C.c_char_p if name == "bpm_error_string" else C.c_int
+        if L.bpm_version() != 1:
+            raise HipLibraryError("libbpmult_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().bpm_error_string(rc)
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,475 @@
+// Fused crossmodal / self attention for BPMulT on gfx950: forward, dQ, dK/dV.
+//
+// Semantics (reference multihead_attention.py:86-130, transformer.py:209-216):
+//   S = Qs K^T  (Qs already carries the dh^-0.5 scale, applied by the Q-projection epilogue)
+//   key j visible to query i  iff  j - i < mask_off   (mask_off = 1 + |S-T|, or "infinite" without attn_mask)
+//   P = softmax_fp32(S) over visible keys;  Pd = dropout(P);  O = Pd V
+// No key-padding mask: zero-padded key rows take part.
+// The [T,S] score matrix never touches HBM: forward keeps a running (max, sum)
+// per query and stores only LSE = max + ln(sum); backward recomputes P from
+// Q, K and LSE.
+//
+// Layouts (HBM):  Q [B,H,T,dhp], K/V [B,H,S,dhp], dO [B,H,T,dhp]  -- CT,
+// head-major, dhp = head_dim padded to 32 with zeros, written by the
+// projection GEMM epilogues.  O, dQ, dK, dV are row-major [(t*B+b), ld]
+// with column h*dh + c: the operand layout of the out-proj / in-proj GEMMs.
+//
+// MFMA orientation ("key on the rows" for forward and dQ, "key on the lane"
+// for dK/dV; cdna_hip_programming.md Appendix B): the score tile is produced
+// with the reduction index of the NEXT product on its register rows, so P / dS
+// feed the second MFMA straight from the accumulator registers (pack_rows)
+// and the other operand is read transposed from the LDS image (read_tr).
+//   forward / dQ : S^T = K Qs^T   -> rows = keys, lane = query
+//                  O^T  += V^T  Pd^T      dQ^T += K^T dS^T
+//   dK/dV        : S   = Qs K^T   -> rows = queries, lane = key
+//                  dV^T += dO^T Pd        dK^T += Qs^T dS
+// One wave owns 16 queries (or 16 keys); a 256-thread workgroup owns 64.
+#include "bpm_common.h"
+#include "../../include/bpmult_hip.h"
+
+namespace {
+
+constexpr int NTHREADS = 256;
+constexpr int KT = 64;      // keys per tile (forward / dQ)
+constexpr int QT = 32;      // queries per tile (dK/dV)
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AProb {
+    const char* Q; const char* K; const char* V;
+    char* O; int ldo;
+    float* lse;
+    const char* dO;
+    float* delta;
+    char* dQ; int lddq;
+    char* dK; int lddk;
+    char* dV; int lddv;
+    int B, H, T, S, dh;
+    int mask_off;
+    float dq_scale;
+    DropCfg drop;
+    int blk0, nblk;     // block prefix / blocks per (b,h)
+};
+struct AGroup {
+    int nprob;
+    AProb p[BPM_MAX_GROUP];
+};
+
+template <typename CT, int DHP> struct Cfg {
+    static constexpr int SZ = sizeof(CT);
+    static constexpr int NKS = DHP / Tr<CT>::KSTEP;        // k-steps over head_dim
+    static constexpr int ND = DHP / 16;                     // 16-wide head_dim tiles
+    static constexpr int ROWB = DHP * SZ;                   // bytes per head row
+    static constexpr int STRIDE = ROWB + Tr<CT>::TR_PAD_B;  // LDS image row stride
+    static constexpr int CPR = ROWB / 16;                   // chunks per row
+};
+
+// cooperative copy of `rows` head rows (global row index row0.., bound nrows) into an LDS image
+template <typename CT, int DHP, int ROWS>
+BPM_DEV void load_rows(char* img, const char* src, int row0, int nrows, int tid) {
+    typedef Cfg<CT, DHP> C;
+    constexpr int N = ROWS * C::CPR;
+#pragma unroll
+    for (int c = tid; c < N; c += NTHREADS) {
+        const int row = c / C::CPR, cc = c % C::CPR;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (row0 + row < nrows) v = *(const u32x4*)(src + (size_t)(row0 + row) * C::ROWB + cc * 16);
+        *(u32x4*)(img + row * C::STRIDE + cc * 16) = v;
+    }
+}
+
+// operand chunk straight from a head-major global row (zero beyond nrows)
+template <typename CT, int DHP>
+BPM_DEV typename Tr<CT>::frag load_frag(const char* src, int row, int nrows, int ks, int g) {
+    typedef Cfg<CT, DHP> C;
+    if (row >= nrows) return Tr<CT>::zero();
+    return *(const typename Tr<CT>::frag*)(src + (size_t)row * C::ROWB + ks * 64 + g * 16);
+}
+
+BPM_DEV const AProb& pick(const AGroup& grp, int& bid) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.nprob; ++i)
+        if (bid >= grp.p[i].blk0) pi = i;
+    bid -= grp.p[pi].blk0;
+    return grp.p[pi];
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <typename CT, int DHP>
+__global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
+    typedef Cfg<CT, DHP> C;
+    typedef typename Tr<CT>::frag frag;
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
+    char* kimg = smem;
+    char* vimg = smem + KT * C::STRIDE;
+
+    int bid = blockIdx.x;
+    const AProb& P = pick(grp, bid);
+    const int bh = bid / P.nblk, qb = bid % P.nblk;
+    const int b = bh / P.H, h = bh % P.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int q = qb * 64 + wave * 16 + c;            // this lane's query
+    const char* Qh = P.Q + (size_t)bh * P.T * C::ROWB;
+    const char* Kh = P.K + (size_t)bh * P.S * C::ROWB;
+    const char* Vh = P.V + (size_t)bh * P.S * C::ROWB;
+
+    frag qf[C::NKS];
+#pragma unroll
+    for (int s = 0; s < C::NKS; ++s) qf[s] = load_frag<CT, DHP>(Qh, q, P.T, s, g);
+
+    f32x4 o[C::ND];
+#pragma unroll
+    for (int n = 0; n < C::ND; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int q_hi = min(P.T, qb * 64 + 64) - 1;
+    const long jmax = min((long)P.S - 1, (long)q_hi + P.mask_off - 1);
+    const int ntile = (int)(jmax / KT) + 1;
+    const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
+
+#pragma unroll 1
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();
+        load_rows<CT, DHP, KT>(kimg, Kh, kt * KT, P.S, tid);
+        load_rows<CT, DHP, KT>(vimg, Vh, kt * KT, P.S, tid);
+        __syncthreads();
+
+        f32x4 st[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < C::NKS; ++s) a = Tr<CT>::mma(read_rowfrag<CT>(kimg, C::STRIDE, 16 * n, s, lane), qf[s], a);
+            st[n] = a;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kt * KT + 16 * n + 4 * g + r;
+                const bool vis = (j < P.S) && ((long)j - q < (long)P.mask_off);
+                st[n][r] = vis ? st[n][r] : -INFINITY;
+                mx = fmaxf(mx, st[n][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * LOG2E);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f((st[n][r] - m_new) * LOG2E);
+                psum += p;
+                const int j = kt * KT + 16 * n + 4 * g + r;
+                st[n][r] = p * bpm_drop_mult(P.drop, drow + (uint32_t)j);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n) o[n] *= alpha;
+        // O^T += V^T Pd^T : k = keys of this tile
+#pragma unroll
+        for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
+            const frag pf = Tr<CT>::pack_rows(st, ks);
+#pragma unroll
+            for (int n = 0; n < C::ND; ++n)
+                o[n] = Tr<CT>::mma(Tr<CT>::read_tr(vimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, o[n]);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    if (q < P.T) {
+        const float inv = 1.f / l_run;
+        CT* orow = (CT*)P.O + ((size_t)q * P.B + b) * P.ldo + h * P.dh;
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * n + 4 * g + r;
+                if (d < P.dh) orow[d] = Tr<CT>::from_f(o[n][r] * inv);
+            }
+        if (g == 0) P.lse[(size_t)bh * P.T + q] = m_run + logf(l_run);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward, dQ (and delta = rowsum(dO * O))
+// ---------------------------------------------------------------------------
+template <typename CT, int DHP>
+__global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp) {
+    typedef Cfg<CT, DHP> C;
+    typedef typename Tr<CT>::frag frag;
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
+    char* kimg = smem;
+    char* vimg = smem + KT * C::STRIDE;
+
+    int bid = blockIdx.x;
+    const AProb& P = pick(grp, bid);
+    const int bh = bid / P.nblk, qb = bid % P.nblk;
+    const int b = bh / P.H, h = bh % P.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int q = qb * 64 + wave * 16 + c;
+    const char* Qh = P.Q + (size_t)bh * P.T * C::ROWB;
+    const char* dOh = P.dO + (size_t)bh * P.T * C::ROWB;
+    const char* Kh = P.K + (size_t)bh * P.S * C::ROWB;
+    const char* Vh = P.V + (size_t)bh * P.S * C::ROWB;
+
+    frag qf[C::NKS], dof[C::NKS];
+    float delta = 0.f;
+#pragma unroll
+    for (int s = 0; s < C::NKS; ++s) {
+        qf[s] = load_frag<CT, DHP>(Qh, q, P.T, s, g);
+        dof[s] = load_frag<CT, DHP>(dOh, q, P.T, s, g);
+        if (q < P.T) {
+            const CT* orow = (const CT*)P.O + ((size_t)q * P.B + b) * P.ldo + h * P.dh;
+#pragma unroll
+            for (int j = 0; j < Tr<CT>::EPC; ++j) {
+                const int d = s * Tr<CT>::KSTEP + g * Tr<CT>::EPC + j;
+                if (d < P.dh) delta += Tr<CT>::to_f(dof[s][j]) * Tr<CT>::to_f(orow[d]);
+            }
+        }
+    }
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    const float lse = (q < P.T) ? P.lse[(size_t)bh * P.T + q] : 0.f;
+    if (q < P.T && g == 0) P.delta[(size_t)bh * P.T + q] = delta;
+
+    f32x4 dq[C::ND];
+#pragma unroll
+    for (int n = 0; n < C::ND; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int q_hi = min(P.T, qb * 64 + 64) - 1;
+    const long jmax = min((long)P.S - 1, (long)q_hi + P.mask_off - 1);
+    const int ntile = (int)(jmax / KT) + 1;
+    const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
+
+#pragma unroll 1
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();
+        load_rows<CT, DHP, KT>(kimg, Kh, kt * KT, P.S, tid);
+        load_rows<CT, DHP, KT>(vimg, Vh, kt * KT, P.S, tid);
+        __syncthreads();
+        f32x4 ds[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < C::NKS; ++s) {
+                s_ = Tr<CT>::mma(read_rowfrag<CT>(kimg, C::STRIDE, 16 * n, s, lane), qf[s], s_);
+                dp = Tr<CT>::mma(read_rowfrag<CT>(vimg, C::STRIDE, 16 * n, s, lane), dof[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kt * KT + 16 * n + 4 * g + r;
+                const bool vis = (j < P.S) && ((long)j - q < (long)P.mask_off);
+                const float p = vis ? exp2f((s_[r] - lse) * LOG2E) : 0.f;
+                const float dm = bpm_drop_mult(P.drop, drow + (uint32_t)j);
+                ds[n][r] = p * (dp[r] * dm - delta);
+            }
+        }
+        // dQ^T += K^T dS^T
+#pragma unroll
+        for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
+            const frag df = Tr<CT>::pack_rows(ds, ks);
+#pragma unroll
+            for (int n = 0; n < C::ND; ++n)
+                dq[n] = Tr<CT>::mma(Tr<CT>::read_tr(kimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dq[n]);
+        }
+    }
+    if (q < P.T) {
+        CT* row = (CT*)P.dQ + ((size_t)q * P.B + b) * P.lddq + h * P.dh;
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * n + 4 * g + r;
+                if (d < P.dh) row[d] = Tr<CT>::from_f(dq[n][r] * P.dq_scale);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward, dK and dV
+// ---------------------------------------------------------------------------
+template <typename CT, int DHP>
+__global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp) {
+    typedef Cfg<CT, DHP> C;
+    typedef typename Tr<CT>::frag frag;
+    __shared__ __attribute__((aligned(16))) char smem[2 * QT * C::STRIDE + 2 * QT * 4];
+    char* qimg = smem;
+    char* doimg = smem + QT * C::STRIDE;
+    float* s_lse = (float*)(smem + 2 * QT * C::STRIDE);
+    float* s_del = s_lse + QT;
+
+    int bid = blockIdx.x;
+    const AProb& P = pick(grp, bid);
+    const int bh = bid / P.nblk, kb = bid % P.nblk;
+    const int b = bh / P.H, h = bh % P.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int j = kb * 64 + wave * 16 + c;            // this lane's key
+    const char* Qh = P.Q + (size_t)bh * P.T * C::ROWB;
+    const char* dOh = P.dO + (size_t)bh * P.T * C::ROWB;
+    const char* Kh = P.K + (size_t)bh * P.S * C::ROWB;
+    const char* Vh = P.V + (size_t)bh * P.S * C::ROWB;
+
+    frag kf[C::NKS], vf[C::NKS];
+#pragma unroll
+    for (int s = 0; s < C::NKS; ++s) {
+        kf[s] = load_frag<CT, DHP>(Kh, j, P.S, s, g);
+        vf[s] = load_frag<CT, DHP>(Vh, j, P.S, s, g);
+    }
+    f32x4 dk[C::ND], dv[C::ND];
+#pragma unroll
+    for (int n = 0; n < C::ND; ++n) { dk[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // first query that can see any key of this block: i > k0 - mask_off
+    const long i_lo = max(0L, (long)kb * 64 - (long)P.mask_off + 1);
+    const int qt_lo = (int)(i_lo / QT);
+    const int qt_hi = (P.T + QT - 1) / QT;
+
+#pragma unroll 1
+    for (int qt = qt_lo; qt < qt_hi; ++qt) {
+        __syncthreads();
+        load_rows<CT, DHP, QT>(qimg, Qh, qt * QT, P.T, tid);
+        load_rows<CT, DHP, QT>(doimg, dOh, qt * QT, P.T, tid);
+        if (tid < QT) {
+            const int i = qt * QT + tid;
+            s_lse[tid] = i < P.T ? P.lse[(size_t)bh * P.T + i] : 0.f;
+            s_del[tid] = i < P.T ? P.delta[(size_t)bh * P.T + i] : 0.f;
+        }
+        __syncthreads();
+        f32x4 pd[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < C::NKS; ++s) {
+                s_ = Tr<CT>::mma(read_rowfrag<CT>(qimg, C::STRIDE, 16 * u, s, lane), kf[s], s_);
+                dp = Tr<CT>::mma(read_rowfrag<CT>(doimg, C::STRIDE, 16 * u, s, lane), vf[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = 16 * u + 4 * g + r;
+                const int i = qt * QT + il;
+                const bool vis = (i < P.T) && (j < P.S) && ((long)j - i < (long)P.mask_off);
+                const float p = vis ? exp2f((s_[r] - s_lse[il]) * LOG2E) : 0.f;
+                const float dm = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)i) * (uint32_t)P.S + (uint32_t)j);
+                pd[u][r] = p * dm;
+                ds[u][r] = p * (dp[r] * dm - s_del[il]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < QT / Tr<CT>::KSTEP; ++ks) {
+            const frag pf = Tr<CT>::pack_rows(pd, ks);
+            const frag df = Tr<CT>::pack_rows(ds, ks);
+#pragma unroll
+            for (int n = 0; n < C::ND; ++n) {
+                dv[n] = Tr<CT>::mma(Tr<CT>::read_tr(doimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, dv[n]);
+                dk[n] = Tr<CT>::mma(Tr<CT>::read_tr(qimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dk[n]);
+            }
+        }
+    }
+    if (j < P.S) {
+        CT* krow = (CT*)P.dK + ((size_t)j * P.B + b) * P.lddk + h * P.dh;
+        CT* vrow = (CT*)P.dV + ((size_t)j * P.B + b) * P.lddv + h * P.dh;
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * n + 4 * g + r;
+                if (d < P.dh) {
+                    krow[d] = Tr<CT>::from_f(dk[n][r]);
+                    vrow[d] = Tr<CT>::from_f(dv[n][r]);
+                }
+            }
+    }
+}
+
+int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S, int* total) {
+    if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
+    g.nprob = nprob;
+    int blk = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const bpm_attn_problem& q = probs[i];
+        AProb& p = g.p[i];
+        if (q.B < 1 || q.H < 1 || q.T < 1 || q.S < 1 || q.dh < 1 || q.dh > q.dhp) return BPM_ERR_ARG;
+        if (q.dhp != probs[0].dhp) return BPM_ERR_ARG;
+        p.Q = (const char*)q.Q; p.K = (const char*)q.K; p.V = (const char*)q.V;
+        p.O = (char*)q.O; p.ldo = q.ldo; p.lse = q.lse;
+        p.dO = (const char*)q.dO; p.delta = q.delta;
+        p.dQ = (char*)q.dQ; p.lddq = q.lddq; p.dK = (char*)q.dK; p.lddk = q.lddk; p.dV = (char*)q.dV; p.lddv = q.lddv;
+        p.B = q.B; p.H = q.H; p.T = q.T; p.S = q.S; p.dh = q.dh;
+        p.mask_off = q.mask_off > 0 ? q.mask_off : (1 << 30);
+        p.dq_scale = q.dq_scale;
+        p.drop.thresh = 0; p.drop.key = 0; p.drop.inv_keep = 1.f;
+        if (q.drop_p > 0.f) {
+            p.drop.thresh = (uint32_t)(q.drop_p * 16777216.0 + 0.5);
+            p.drop.key = bpm_host_drop_key(q.drop_seed, q.drop_site);
+            p.drop.inv_keep = 1.f / (1.f - q.drop_p);
+        }
+        p.nblk = ((blocks_over_S ? q.S : q.T) + 63) / 64;
+        p.blk0 = blk;
+        blk += p.nblk * q.B * q.H;
+    }
+    *total = blk;
+    return 0;
+}
+
+template <typename CT>
+int dispatch(int which, int dhp, const AGroup& g, int total, hipStream_t s) {
+    dim3 grid(total), block(NTHREADS);
+#define BPM_ATTN_CASE(D)                                                                                        \
+    case D:                                                                                                     \
+        if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<CT, D>), grid, block, 0, s, g);                     \
+        else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, D>), grid, block, 0, s, g);             \
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, D>), grid, block, 0, s, g);                            \
+        break;
+    switch (dhp) {
+        BPM_ATTN_CASE(32)
+        BPM_ATTN_CASE(64)
+        BPM_ATTN_CASE(128)
+        default: return BPM_ERR_ARG;
+    }
+#undef BPM_ATTN_CASE
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob, void* stream) {
+    AGroup g;
+    int total = 0;
+    int rc = fill(g, probs, nprob, 0, &total);
+    if (rc) return rc;
+    for (int i = 0; i < nprob; ++i)
+        if (!probs[i].Q || !probs[i].K || !probs[i].V || !probs[i].O || !probs[i].lse) return BPM_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == BPM_BF16 ? dispatch<bf16_t>(0, probs[0].dhp, g, total, s) : dispatch<float>(0, probs[0].dhp, g, total, s);
+}
+
+// dQ first (it also produces delta), then dK/dV on the same stream.
+extern "C" int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs, int nprob, void* stream) {
+    AGroup g;
+    int total = 0;
+    int rc = fill(g, probs, nprob, 0, &total);
+    if (rc) return rc;
+    for (int i = 0; i < nprob; ++i) {
+        const bpm_attn_problem& q = probs[i];
+        if (!q.Q || !q.K || !q.V || !q.O || !q.lse || !q.dO || !q.delta || !q.dQ || !q.dK || !q.dV) return BPM_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    rc = dtype == BPM_BF16 ? dispatch<bf16_t>(1, probs[0].dhp, g, total, s) : dispatch<float>(1, probs[0].dhp, g, total, s);
+    if (rc) return rc;
+    rc = fill(g, probs, nprob, 1, &total);
+    if (rc) return rc;
+    return dtype == BPM_BF16 ? dispatch<bf16_t>(2, probs[0].dhp, g, total, s) : dispatch<float>(2, probs[0].dhp, g, total, s);
+}

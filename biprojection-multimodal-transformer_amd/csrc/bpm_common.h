@@ -1,0 +1,166 @@
+// Device-side helpers shared by every BPMulT gfx950 kernel.
+//
+// Compute type CT is either float (parity mode: exact f32 MFMA 16x16x4) or
+// __bf16 (throughput mode: MFMA 16x16x32 with f32 accumulation).  Everything is
+// written in units of a 16-byte "chunk" (8 bf16 / 4 f32) and a 64-byte "k-step"
+// (32 bf16 / 16 f32), so both types share addressing.
+//
+// MFMA 16x16 lane maps (cdna_hip_programming.md section 3), lane l: r = l & 15, g = l >> 4
+//   bf16 16x16x32: A[row r][k = 8g + j], B[k = 8g + j][col r], j = 0..7
+//   f32  16x16x4 : A[row r][k = g],      B[k = g][col r]
+//   C/D           : col = r, row = 4g + reg (reg = 0..3)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define BPM_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// Counter-hash dropout.  keep(idx) is a pure function of (seed, site, idx), so
+// forward and backward kernels with different tilings regenerate one mask.
+// 24-bit threshold: P(drop) = round(p * 2^24) / 2^24.
+// ---------------------------------------------------------------------------
+struct DropCfg {
+    uint32_t key;     // mixed (seed, site); 0 with thresh 0 when disabled
+    uint32_t thresh;  // drop when (hash >> 8) < thresh
+    float inv_keep;   // 1 / (1 - p)
+};
+
+BPM_DEV uint32_t bpm_hash32(uint32_t idx, uint32_t key) {
+    uint32_t h = idx * 0x9E3779B1u + key;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+// host side: fold (seed, site) into the 32-bit hash key
+static inline uint32_t bpm_host_drop_key(uint64_t seed, uint32_t site) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z ^ (z >> 32));
+}
+// multiplier applied to a kept element; 0 for a dropped one
+BPM_DEV float bpm_drop_mult(const DropCfg& d, uint32_t idx) {
+    if (d.thresh == 0) return 1.0f;
+    return ((bpm_hash32(idx, d.key) >> 8) < d.thresh) ? 0.0f : d.inv_keep;
+}
+
+// ---------------------------------------------------------------------------
+// per-type traits
+// ---------------------------------------------------------------------------
+template <typename CT> struct Tr;
+
+template <> struct Tr<float> {
+    typedef f32x4 frag;                 // one 16-byte chunk
+    static constexpr int EPC = 4;       // elements per chunk
+    static constexpr int KSTEP = 16;    // elements per 64-byte k-step
+    static constexpr int CT_PER_KSTEP = 1;  // 16-row C sub-tiles that make one k-step
+    static BPM_DEV float to_f(float v) { return v; }
+    static BPM_DEV float from_f(float v) { return v; }
+    static BPM_DEV frag zero() { return frag{0.f, 0.f, 0.f, 0.f}; }
+    // acc += A(16 x KSTEP) * B(KSTEP x 16); element j of both frags is the same k
+    static BPM_DEV f32x4 mma(frag a, frag b, f32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+        return acc;
+    }
+    // C sub-tiles (rows 4g+reg) -> operand chunk whose element j is row 4g + j of sub-tile ks
+    static BPM_DEV frag pack_rows(const f32x4* ct, int ks) { return ct[ks]; }
+    // Operand chunk read from a k-strided LDS image [krow][col] (col contiguous):
+    // element j <- image[krow0 + 4g + j][col0 + r].  `second` is ignored for f32.
+    static BPM_DEV frag read_tr(const char* img, int stride_b, int krow0, int col0, int lane, int /*second*/) {
+        const int r = lane & 15, g = lane >> 4;
+        const char* p = img + (size_t)(krow0 + 4 * g) * stride_b + (col0 + r) * 4;
+        frag f;
+        f[0] = *(const float*)(p);
+        f[1] = *(const float*)(p + stride_b);
+        f[2] = *(const float*)(p + 2 * stride_b);
+        f[3] = *(const float*)(p + 3 * stride_b);
+        return f;
+    }
+    static constexpr int TR_NATURAL = 0, TR_CTILE = 0;
+    static constexpr int TR_PAD_B = 16;   // row pad (bytes) of a k-strided image
+};
+
+template <> struct Tr<bf16_t> {
+    typedef bf16x8 frag;
+    static constexpr int EPC = 8;
+    static constexpr int KSTEP = 32;
+    static constexpr int CT_PER_KSTEP = 2;
+    static BPM_DEV float to_f(bf16_t v) { return (float)v; }
+    static BPM_DEV bf16_t from_f(float v) { return (bf16_t)v; }
+    static BPM_DEV frag zero() {
+        frag f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (bf16_t)0.f;
+        return f;
+    }
+    static BPM_DEV f32x4 mma(frag a, frag b, f32x4 acc) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+    // element j<4 is row 4g+j of sub-tile 2ks, element j>=4 is row 4g+j-4 of sub-tile 2ks+1
+    static BPM_DEV frag pack_rows(const f32x4* ct, int ks) {
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[j] = (bf16_t)ct[2 * ks][j];
+            f[4 + j] = (bf16_t)ct[2 * ks + 1][j];
+        }
+        return f;
+    }
+    // ds_read_b64_tr_b16 (T10): per 16-lane group, lane 4q+p supplies the
+    // address of row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
+    //   second = 4  ("natural"): element j <- image[krow0 + 8g + j][col0 + r]
+    //   second = 16 ("ctile")  : element j<4 <- image[krow0 + 4g + j][..], j>=4 <- image[krow0 + 16 + 4g + j-4][..]
+    static BPM_DEV frag read_tr(const char* img, int stride_b, int krow0, int col0, int lane, int second) {
+        const int i = lane & 15, g = lane >> 4;
+        const int q = i >> 2, p = i & 3;
+        const int row = krow0 + (second == 4 ? 8 * g : 4 * g) + q;
+        const char* a0 = img + (size_t)row * stride_b + (col0 + 4 * p) * 2;
+        const char* a1 = a0 + (size_t)second * stride_b;
+        typedef bf16x4 __attribute__((address_space(3))) * lds4;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a0));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a1));
+        frag f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        return f;
+    }
+    static constexpr int TR_NATURAL = 4, TR_CTILE = 16;
+    static constexpr int TR_PAD_B = 32;
+};
+
+// k-contiguous operand chunk from an LDS image [row][k] (row stride stride_b):
+// lane (r, g) reads the 16 bytes at row (row0 + r), k-step byte offset ks*64 + 16g.
+template <typename CT>
+BPM_DEV typename Tr<CT>::frag read_rowfrag(const char* img, int stride_b, int row0, int ks, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    return *(const typename Tr<CT>::frag*)(img + (size_t)(row0 + r) * stride_b + ks * 64 + g * 16);
+}
+
+BPM_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LDS byte offset of a generic pointer into __shared__ memory
+BPM_DEV uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)p; }
+
+#define BPM_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)

@@ -1,0 +1,334 @@
+// Grouped MFMA GEMM for the BPMulT hot path (gfx950).
+//
+// One launch computes up to BPM_MAX_GROUP independent problems (the six
+// crossmodal encoders of a level run in lock-step), each
+//   C[M,N] = epilogue( sum_k X(m,k) * Y(n,k) )
+// in three operand arrangements
+//   NT: X = A[M,K] (k contiguous), Y = W[N,K] (k contiguous)   forward  y = x W^T
+//   NN: X = A[M,K] (k contiguous), Y = B[K,N] (n contiguous)   dgrad    dx = dy W
+//   TN: X = A[K,M] (m contiguous), Y = B[K,N] (n contiguous)   wgrad    dW = dy^T x
+// Operands are CT (= float: exact f32 MFMA 16x16x4, or bf16: MFMA 16x16x32,
+// f32 accumulate) in row-major buffers whose leading dimension is a multiple
+// of 32 elements with zero padding, so tiles are moved in whole 16-byte
+// chunks with chunk-granular guards only.
+//
+// Tile: 128(M) x 64(N) per 256-thread workgroup, 4 waves as 2x2, each wave
+// 64x32 = 4x2 MFMA tiles.  k is consumed 128 bytes (2 k-steps) per stage
+// through double-buffered, register-staged LDS images:
+//   k-contiguous operand  -> image [rows][128 B + 16 B pad]  read with ds_read_b128
+//   k-strided   operand  -> image [k][rows*sz + pad]        read transposed
+//                            (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32)
+// The MFMA is issued "swapped" (Y rows as the A operand, X rows as the B
+// operand) so that a lane owns 4 consecutive n of one output row m and the
+// epilogue stores 16 B (f32) / 8 B (bf16) vectors.
+//
+// Epilogue (all optional, per problem): + bias[n], + bias[m], * alpha, ReLU,
+// gate by (aux > 0) * s (ReLU/dropout backward), dropout, + residual, then
+// store as f32 row-major (optionally += or atomicAdd for split-K), CT
+// row-major (pad columns zeroed) or CT head-major [B,H,T,dhp] (attention
+// operand layout).
+#include "bpm_common.h"
+#include "../../include/bpmult_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
+constexpr int KSTEPS = 2;                 // 64-byte k-steps per stage
+constexpr int BKB = KSTEPS * 64;          // bytes of k per stage and row
+constexpr int NTHREADS = 256;
+constexpr int TM = BM / WM / 16;          // 4 MFMA tiles along m per wave
+constexpr int TN = BN / WN / 16;          // 2 along n
+constexpr int ROW_STRIDE = BKB + 16;      // k-contiguous image row stride (bytes)
+
+struct Prob {
+    const char* X; const char* Y; char* C;
+    int M, N, K;
+    int ldx, ldy, ldc;
+    const float* bias_n; const float* bias_m;
+    const float* resid; int ldr;
+    const char* gate; int ldg; float gate_scale;
+    float alpha;
+    DropCfg drop;
+    int flags;
+    int out_kind;
+    int hB, hH, hT, hdh, hdhp;
+    int tile0, tiles_m, tiles_n, splitk;
+};
+
+struct Group {
+    int nprob;
+    int total_tiles;
+    Prob p[BPM_MAX_GROUP];
+};
+
+template <typename CT, bool KCONTIG, int ROWS>
+struct Side {
+    static constexpr int SZ = sizeof(CT);
+    static constexpr int EPC = Tr<CT>::EPC;
+    static constexpr int BK = KSTEPS * Tr<CT>::KSTEP;                    // elements of k per stage
+    static constexpr int STRIDE = KCONTIG ? ROW_STRIDE : ROWS * SZ + Tr<CT>::TR_PAD_B;
+    static constexpr int IMG_BYTES = KCONTIG ? ROWS * ROW_STRIDE : BK * STRIDE;
+    static constexpr int NCHUNK = ROWS * BKB / 16;
+    static constexpr int PER_THREAD = NCHUNK / NTHREADS;
+    static_assert(NCHUNK % NTHREADS == 0, "tile chunks must divide over the workgroup");
+
+    // global -> registers.  rows_bound: valid rows of this side (M or N);
+    // k_lo/k_hi: contraction range of this block; ld: leading dim (elements).
+    static BPM_DEV void load(const char* base, int ld, int row0, int rows_bound, int k0, int k_hi, int kext,
+                             u32x4 (&reg)[PER_THREAD], int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NTHREADS;
+            bool ok;
+            size_t off;
+            if (KCONTIG) {
+                const int row = c / (BKB / 16), kc = c % (BKB / 16);
+                const int k = k0 + kc * EPC;
+                ok = (row0 + row < rows_bound) && (k < k_hi) && (k < kext);
+                off = ((size_t)(row0 + row) * ld + k) * SZ;
+            } else {
+                constexpr int CPR = ROWS * SZ / 16;
+                const int kr = c / CPR, cc = c % CPR;
+                const int col = row0 + cc * EPC;
+                ok = (k0 + kr < k_hi) && (col + EPC <= ld) && (col < rows_bound);
+                off = ((size_t)(k0 + kr) * ld + col) * SZ;
+            }
+            reg[i] = ok ? *(const u32x4*)(base + off) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    static BPM_DEV void store(char* img, const u32x4 (&reg)[PER_THREAD], int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NTHREADS;
+            int dst;
+            if (KCONTIG) {
+                const int row = c / (BKB / 16), kc = c % (BKB / 16);
+                dst = row * ROW_STRIDE + kc * 16;
+            } else {
+                constexpr int CPR = ROWS * SZ / 16;
+                const int kr = c / CPR, cc = c % CPR;
+                dst = kr * STRIDE + cc * 16;
+            }
+            *(u32x4*)(img + dst) = reg[i];
+        }
+    }
+    // operand chunk for the 16 rows starting at r0, k-step ks of the stage
+    static BPM_DEV typename Tr<CT>::frag frag(const char* img, int r0, int ks, int lane) {
+        if (KCONTIG) return read_rowfrag<CT>(img, ROW_STRIDE, r0, ks, lane);
+        return Tr<CT>::read_tr(img, STRIDE, ks * Tr<CT>::KSTEP, r0, lane, Tr<CT>::TR_NATURAL);
+    }
+};
+
+template <typename CT>
+BPM_DEV void store_ct4(char* C, size_t off_elems, const float (&v)[4], int nvalid) {
+    CT* p = (CT*)C + off_elems;
+    if (nvalid == 4 && ((off_elems & 3) == 0)) {
+        if constexpr (sizeof(CT) == 4) {
+            *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            *(bf16x4*)p = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) p[r] = Tr<CT>::from_f(v[r]);
+    }
+}
+
+template <typename CT, bool XK, bool YK>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
+    typedef Side<CT, XK, BM> SX;
+    typedef Side<CT, YK, BN> SY;
+    constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // block -> (problem, split, tile)
+    int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.nprob; ++i)
+        if (bid >= grp.p[i].tile0) pi = i;
+    const Prob& P = grp.p[pi];
+    bid -= P.tile0;
+    const int tiles = P.tiles_m * P.tiles_n;
+    const int split = bid / tiles;
+    const int t = bid % tiles;
+    const int m0 = (t / P.tiles_n) * BM, n0 = (t % P.tiles_n) * BN;
+
+    constexpr int BK = SX::BK;
+    const int nkt_all = (P.K + BK - 1) / BK;
+    const int per = (nkt_all + P.splitk - 1) / P.splitk;
+    const int kt_lo = split * per;
+    const int kt_hi = min(nkt_all, kt_lo + per);
+    const int kext = (P.K + Tr<CT>::EPC - 1) / Tr<CT>::EPC * Tr<CT>::EPC;
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 rx[SX::PER_THREAD], ry[SY::PER_THREAD];
+    if (kt_lo < kt_hi) {
+        SX::load(P.X, P.ldx, m0, P.M, kt_lo * BK, P.K, kext, rx, tid);
+        SY::load(P.Y, P.ldy, n0, P.N, kt_lo * BK, P.K, kext, ry, tid);
+        SX::store(smem, rx, tid);
+        SY::store(smem + SX::IMG_BYTES, ry, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const bool more = kt + 1 < kt_hi;
+        if (more) {
+            SX::load(P.X, P.ldx, m0, P.M, (kt + 1) * BK, P.K, kext, rx, tid);
+            SY::load(P.Y, P.ldy, n0, P.N, (kt + 1) * BK, P.K, kext, ry, tid);
+        }
+        const char* ix = smem + cur * STAGE;
+        const char* iy = ix + SX::IMG_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            typename Tr<CT>::frag fx[TM], fy[TN];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) fx[b] = SX::frag(ix, wm * (BM / WM) + 16 * b, ks, lane);
+#pragma unroll
+            for (int a = 0; a < TN; ++a) fy[a] = SY::frag(iy, wn * (BN / WN) + 16 * a, ks, lane);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] = Tr<CT>::mma(fy[a], fx[b], acc[a][b]);
+        }
+        if (more) {
+            char* nx = smem + (cur ^ 1) * STAGE;
+            SX::store(nx, rx, tid);
+            SY::store(nx + SX::IMG_BYTES, ry, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------- epilogue ----------------
+    const int r = lane & 15, g = lane >> 4;
+    const bool lead = (split == 0);
+    const bool atomic = (P.flags & BPM_GEMM_ATOMIC) != 0;
+    const bool accum = (P.flags & BPM_GEMM_ACCUM) != 0;
+    const bool relu = (P.flags & BPM_GEMM_RELU) != 0;
+    if (kt_lo >= kt_hi && !lead) return;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * (BM / WM) + 16 * b + r;
+        if (m >= P.M) continue;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int nb = n0 + wn * (BN / WN) + 16 * a + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + q;
+                float x = acc[a][b][q];
+                if (n < P.N) {
+                    if (lead) {
+                        if (P.bias_n) x += P.bias_n[n];
+                        if (P.bias_m) x += P.bias_m[m];
+                    }
+                    x *= P.alpha;
+                    if (relu) x = fmaxf(x, 0.f);
+                    if (P.gate) {
+                        const float gv = Tr<CT>::to_f(((const CT*)P.gate)[(size_t)m * P.ldg + n]);
+                        x = gv > 0.f ? x * P.gate_scale : 0.f;
+                    }
+                    x *= bpm_drop_mult(P.drop, (uint32_t)m * (uint32_t)P.N + (uint32_t)n);
+                    if (P.resid && lead) x += P.resid[(size_t)m * P.ldr + n];
+                } else {
+                    x = 0.f;
+                }
+                v[q] = x;
+            }
+            if (P.out_kind == BPM_OUT_F32) {
+                float* c = (float*)P.C + (size_t)m * P.ldc + nb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (nb + q >= P.N) continue;
+                    if (atomic) atomicAdd(c + q, v[q]);
+                    else if (accum) c[q] += v[q];
+                    else c[q] = v[q];
+                }
+            } else if (P.out_kind == BPM_OUT_CT) {
+                const int nvalid = min(4, P.ldc - nb);   // pad columns [N, ldc) get zeros
+                if (nvalid > 0) store_ct4<CT>(P.C, (size_t)m * P.ldc + nb, v, nvalid);
+            } else {  // BPM_OUT_HEADS: m = t*B + b, n = h*dh + c  ->  [B,H,T,dhp]
+                const int tt = m / P.hB, bb = m % P.hB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + q;
+                    if (n >= P.N) continue;
+                    const int h = n / P.hdh, c = n % P.hdh;
+                    ((CT*)P.C)[(((size_t)bb * P.hH + h) * P.hT + tt) * P.hdhp + c] = Tr<CT>::from_f(v[q]);
+                }
+            }
+        }
+    }
+}
+
+template <typename CT>
+int launch(int variant, const Group& g, hipStream_t s) {
+    dim3 grid(g.total_tiles), block(NTHREADS);
+    switch (variant) {
+        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<CT, true, true>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<CT, true, false>), grid, block, 0, s, g); break;
+        case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<CT, false, false>), grid, block, 0, s, g); break;
+        default: return BPM_ERR_ARG;
+    }
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs, int nprob, void* stream) {
+    if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
+    const int sz = dtype == BPM_BF16 ? 2 : 4;
+    Group g;
+    g.nprob = nprob;
+    int tile = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const bpm_gemm_problem& q = probs[i];
+        Prob& p = g.p[i];
+        if (q.M < 1 || q.N < 1 || q.K < 1 || !q.A || !q.B || !q.C) return BPM_ERR_ARG;
+        // operand leading dims must keep every row 16-byte aligned
+        if ((q.lda * sz) % 16 || (q.ldb * sz) % 16) return BPM_ERR_ALIGN;
+        if (((uintptr_t)q.A | (uintptr_t)q.B) & 15) return BPM_ERR_ALIGN;
+        p.X = (const char*)q.A; p.Y = (const char*)q.B; p.C = (char*)q.C;
+        p.M = q.M; p.N = q.N; p.K = q.K;
+        p.ldx = q.lda; p.ldy = q.ldb; p.ldc = q.ldc;
+        p.bias_n = q.bias_n; p.bias_m = q.bias_m;
+        p.resid = q.resid; p.ldr = q.ldr;
+        p.gate = (const char*)q.gate; p.ldg = q.ldg; p.gate_scale = q.gate_scale;
+        p.alpha = q.alpha;
+        p.drop.thresh = 0; p.drop.key = 0; p.drop.inv_keep = 1.f;
+        if (q.drop_p > 0.f) {
+            p.drop.thresh = (uint32_t)(q.drop_p * 16777216.0 + 0.5);
+            p.drop.key = bpm_host_drop_key(q.drop_seed, q.drop_site);
+            p.drop.inv_keep = 1.f / (1.f - q.drop_p);
+        }
+        p.flags = q.flags; p.out_kind = q.out_kind;
+        p.hB = q.heads_B; p.hH = q.heads_H; p.hT = q.heads_T; p.hdh = q.heads_dh; p.hdhp = q.heads_dhp;
+        if (q.out_kind == BPM_OUT_HEADS && (q.heads_B < 1 || q.heads_dh < 1 || q.heads_H * q.heads_dh != q.N)) return BPM_ERR_ARG;
+        p.tiles_m = (q.M + BM - 1) / BM;
+        p.tiles_n = (q.N + BN - 1) / BN;
+        if (q.out_kind == BPM_OUT_CT && p.tiles_n * BN < q.ldc) return BPM_ERR_ARG;
+        p.splitk = q.splitk > 1 ? q.splitk : 1;
+        if (p.splitk > 1 && !((q.flags & BPM_GEMM_ATOMIC) && q.out_kind == BPM_OUT_F32)) return BPM_ERR_ARG;
+        p.tile0 = tile;
+        tile += p.tiles_m * p.tiles_n * p.splitk;
+    }
+    g.total_tiles = tile;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == BPM_BF16 ? launch<bf16_t>(variant, g, s) : launch<float>(variant, g, s);
+}

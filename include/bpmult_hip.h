@@ -1,0 +1,180 @@
+/* bpmult_hip.h -- C ABI of libbpmult_hip.so, the MI355X (gfx950) implementation
+ * of the BPMulT forward/backward hot path.
+ *
+ * The reference (Damorgal/Biprojection-Multimodal-Transformer) is pure Python:
+ * its "FFI" for this path is the set of torch ops called by
+ * bpmult/models/{mmtr,transformer,multihead_attention,position_embedding}.py.
+ * Each entry point below replaces the ops named in its comment (file:line into
+ * the reference); INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer owned by
+ *    the caller (PyTorch allocates); nothing here allocates or frees;
+ *  - every function returns 0 on success, BPM_ERR_* or a hipError_t otherwise
+ *    (bpm_error_string() renders either); nothing is printed;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *    the call returns without synchronising (graph-capturable);
+ *  - `dtype` selects the compute type CT of MFMA operands: BPM_F32 (exact f32
+ *    MFMA 16x16x4 -- parity mode) or BPM_BF16 (MFMA 16x16x32, f32 accumulate);
+ *  - row-major CT buffers that feed a GEMM have a leading dimension that is a
+ *    multiple of 32 elements and ZERO padding columns; residual-stream tensors
+ *    are fp32 [(t*B + b), d] exactly as torch lays out [T,B,d];
+ *  - dropout masks are a pure function of (seed, site, element index)
+ *    (counter hash), so backward regenerates them; drop_p = 0 disables.
+ */
+#ifndef BPMULT_HIP_H
+#define BPMULT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPM_ABI_VERSION 1
+#define BPM_MAX_GROUP 12 /* problems per grouped launch (12 encoders per model) */
+
+enum { BPM_F32 = 0, BPM_BF16 = 1 };
+enum { BPM_ERR_ARG = -1, BPM_ERR_ALIGN = -2 };
+
+int bpm_version(void);
+const char* bpm_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * Grouped GEMM with fused epilogue.
+ * Replaces: F.linear in MultiheadAttention._in_proj / out_proj
+ * (multihead_attention.py:130,152-158), fc1/fc2 (transformer.py:186-190),
+ * nn.Conv1d k=1 projections (mmtr.py:456-458,748-750), the GMU linears
+ * (mmtr.py:189-195), the time-axis nn.Linear maps (mmtr.py:507-508) and the
+ * corresponding autograd backward GEMMs (train.py:394).
+ *   BPM_GEMM_NT: C[M,N] = A[M,K] . B[N,K]^T     (A, B k-contiguous)
+ *   BPM_GEMM_NN: C[M,N] = A[M,K] . B[K,N]
+ *   BPM_GEMM_TN: C[M,N] = A[K,M]^T . B[K,N]
+ * v = ((acc + bias_n[n] + bias_m[m]) * alpha); ReLU; gate; dropout; + resid.
+ * ---------------------------------------------------------------------- */
+enum { BPM_GEMM_NT = 0, BPM_GEMM_NN = 1, BPM_GEMM_TN = 2 };
+enum { BPM_OUT_F32 = 0, BPM_OUT_CT = 1, BPM_OUT_HEADS = 2 };
+enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4 };
+
+typedef struct bpm_gemm_problem {
+    const void* A;          /* CT */
+    const void* B;          /* CT */
+    void* C;                /* fp32 (BPM_OUT_F32) or CT */
+    int M, N, K;
+    int lda, ldb, ldc;      /* elements */
+    const float* bias_n;    /* [N] or NULL */
+    const float* bias_m;    /* [M] or NULL (time-axis Linear) */
+    const float* resid;     /* fp32 [M, ldr] added after dropout, or NULL */
+    int ldr;
+    const void* gate;       /* CT [M, ldg]: v = gate > 0 ? v * gate_scale : 0 (ReLU+dropout backward), or NULL */
+    int ldg;
+    float gate_scale;
+    float alpha;
+    float drop_p;           /* dropout on element index m*N + n */
+    uint64_t drop_seed;
+    uint32_t drop_site;
+    int flags;              /* BPM_GEMM_* */
+    int out_kind;           /* BPM_OUT_* */
+    int splitk;             /* >1 needs BPM_GEMM_ATOMIC + BPM_OUT_F32 into a zeroed / accumulating buffer */
+    /* BPM_OUT_HEADS: row m = t*B + b, column n = h*dh + c  ->  C[b][h][t][c] of [B,H,T,dhp] */
+    int heads_B, heads_H, heads_T, heads_dh, heads_dhp;
+} bpm_gemm_problem;
+
+int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs /* host */, int nprob, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused attention (never materialises the [T,S] scores).
+ * Replaces: torch.bmm / += attn_mask / F.softmax(float) / F.dropout / torch.bmm
+ * (multihead_attention.py:110-126), buffered_future_mask (transformer.py:209-216)
+ * and their backward.  Q [B,H,T,dhp] (pre-scaled by dh^-0.5), K/V [B,H,S,dhp],
+ * dO [B,H,T,dhp]: CT head-major, dhp in {32,64,128}.  O, dQ, dK, dV: CT
+ * row-major [(t*B+b), ld], column h*dh + c.  lse, delta: fp32 [B,H,T].
+ * mask_off: key j visible to query i iff j - i < mask_off (1 + |S-T| with
+ * attn_mask; <= 0 means no mask).
+ * ---------------------------------------------------------------------- */
+typedef struct bpm_attn_problem {
+    const void* Q; const void* K; const void* V;
+    void* O; int ldo;
+    float* lse;
+    const void* dO;         /* backward only */
+    float* delta;           /* backward scratch [B,H,T] */
+    void* dQ; int lddq;     /* receives d(q before scaling) = dQs * dq_scale */
+    void* dK; int lddk;
+    void* dV; int lddv;
+    int B, H, T, S, dh, dhp;
+    int mask_off;
+    float dq_scale;
+    float drop_p;           /* on P, element index ((b*H+h)*T + i)*S + j */
+    uint64_t drop_seed;
+    uint32_t drop_site;
+} bpm_attn_problem;
+
+int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, void* stream);
+int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Input staging.  Replaces x.transpose(1,2) / F.dropout on the text features /
+ * .permute(2,0,1) around the Conv1d projections (mmtr.py:741-753): src fp32
+ * [B,T,C] -> CT [(t*B+b), ld] (zero pad columns), and its backward.
+ * ---------------------------------------------------------------------- */
+int bpm_pack_rows_fwd(int dtype, const float* src, void* dst, int B, int T, int C, int ld,
+                      float drop_p, uint64_t seed, uint32_t site, void* stream);
+int bpm_pack_rows_bwd(const float* g, int ldg, float* dsrc, int B, int T, int C,
+                      float drop_p, uint64_t seed, uint32_t site, void* stream);
+
+/* fp32 master weights [rows, cols] -> CT shadows [rows, ld]; table lives in device memory */
+typedef struct bpm_pack_desc {
+    const void* src;
+    void* dst;
+    int rows, cols, ld;
+    unsigned blk0;          /* first block of this tensor; blocks cover 1024 shadow elements each */
+} bpm_pack_desc;
+int bpm_pack_weights(int dtype, const bpm_pack_desc* table_dev, int ndesc, unsigned total_blocks, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Encoder prologue.  Replaces embed_scale * x + embed_positions(x[:,:,0]) and
+ * F.dropout (transformer.py:66-79; position_embedding.py:8-27,62-76):
+ * out = dropout(scale*x + table[pos]), pos = t+1 if x[t,b,0] != 0 else 0.
+ * `table` is the fp32 sinusoid table [table_rows >= T+1, d] built on the host.
+ * ---------------------------------------------------------------------- */
+int bpm_embed_pos_fwd(const float* x, const float* table, int table_rows, float* out, int T, int B, int d,
+                      float scale, float drop_p, uint64_t seed, uint32_t site, void* stream);
+int bpm_embed_pos_bwd(const float* dy, float* dx, int T, int B, int d, float scale, float drop_p,
+                      uint64_t seed, uint32_t site, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm (nn.LayerNorm(d), eps inside sqrt; transformer.py:91,153,167-172,
+ * 183-185,227-229).  x fp32 [R,d].  out_dtype: BPM_F32 / BPM_BF16 write CT
+ * [R, ldo] with zero pad columns; BPM_OUT_LN_F32 writes plain fp32 [R, ldo].
+ * Backward: dx = add + dLN(dy), dgamma/dbeta accumulated by atomics (may be NULL).
+ * ---------------------------------------------------------------------- */
+#define BPM_OUT_LN_F32 2
+int bpm_ln_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* out, int ldo,
+               float* mean, float* rstd, int R, int d, float eps, void* stream);
+int bpm_ln_bwd(const float* dy, int ldy, const float* x, const float* mean, const float* rstd, const float* gamma,
+               const float* add, float* dx, float* dgamma, float* dbeta, int R, int d, void* stream);
+
+/* y = (a [+ b]) * dropout_mult(r*C + c): CT copy (padded) and/or fp32 copy and/or
+ * column sums (+= by atomics).  Used for residual-dropout backward + bias
+ * gradients (transformer.py:174-175,189-190) and the level 1->2 residual adds
+ * (mmtr.py:799-800). */
+int bpm_rows_cast(int dtype, const float* a, int lda, const float* b, int ldb, void* dst_ct, int ldd,
+                  float* dst_f32, int ldf, float* colsum, int R, int C,
+                  float drop_p, uint64_t seed, uint32_t site, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fusion-GMU gating (GatedMultimodalLayerFeatures.forward, mmtr.py:189-195):
+ * out = z*tanh(a1)*x1 + (1-z)*tanh(a2)*x2, z = sigmoid(ag); a1,a2,ag fp32 [R,d]
+ * are the three bias-free linears (GEMM outputs).  Backward writes da1,da2,dag
+ * as CT [R, ldg] and the direct terms dx1 = dout*z*tanh(a1), dx2 likewise.
+ * ---------------------------------------------------------------------- */
+int bpm_gmu2_fwd(const float* a1, const float* a2, const float* ag, const float* x1, const float* x2,
+                 float* out, int R, int d, void* stream);
+int bpm_gmu2_bwd(int dtype, const float* dout, const float* a1, const float* a2, const float* ag,
+                 const float* x1, const float* x2, void* da1, void* da2, void* dag, int ldg,
+                 float* dx1, float* dx2, int R, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPMULT_HIP_H */

@@ -1,0 +1,299 @@
+"""Per-kernel parity on the MI355X, through the C ABI (ctypes), against fp64/fp32
+torch CPU restatements of the same op.  f32 mode must agree to ~1e-5 (exact f32
+MFMA); bf16 mode is compared against the same maths on bf16-rounded operands.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bpmult_amd import ops  # noqa: E402
+from bpmult_amd.ops import (BPM_BF16, BPM_F32, F_ATOMIC, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,  # noqa: E402
+                            pad32)
+
+DEV = "cuda"
+DT = [BPM_F32, BPM_BF16]
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def to_ct(x, dtype, ld=None):
+    """CPU fp32 [R,C] -> device CT [R,ld] zero padded; also the CT-rounded fp32 copy."""
+    R, Cn = x.shape
+    ld = pad32(Cn) if ld is None else ld
+    buf = torch.zeros(R, ld, dtype=ops.ct_torch(dtype))
+    buf[:, :Cn] = x.to(ops.ct_torch(dtype))
+    return buf.to(DEV), buf[:, :Cn].float()
+
+
+def tol(dtype):
+    return 2e-5 if dtype == BPM_F32 else 1.5e-2
+
+
+def close(got, ref, t, what=""):
+    got, ref = got.detach().cpu().double(), ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite"
+    scale = max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= t * scale, f"{what}: max err {err:.3e} vs tol {t * scale:.3e}"
+
+
+# numpy restatement of the dropout hash (bpm_common.h) -- test infrastructure
+def host_key(seed, site):
+    M = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (site + 1)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return (z ^ (z >> 32)) & 0xFFFFFFFF
+
+
+def drop_mult(shape, p, seed, site):
+    if p <= 0:
+        return torch.ones(shape)
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    h = (idx * 0x9E3779B1 + host_key(seed, site)) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    thresh = int(p * 16777216.0 + 0.5)
+    keep = (h >> 8) >= thresh
+    return torch.from_numpy(np.where(keep, 1.0 / (1.0 - p), 0.0).astype(np.float32)).reshape(shape)
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(200, 300, 300), (520, 70, 35), (129, 65, 1200), (8, 6, 24)])
+def test_gemm_nt_bias_resid(dtype, M, N, K):
+    A, Ar = to_ct(rnd(M, K, seed=1), dtype)
+    W, Wr = to_ct(rnd(N, K, seed=2, scale=K ** -0.5), dtype)
+    bias = rnd(N, seed=3).to(DEV)
+    resid = rnd(M, N, seed=4).to(DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    p = ops.gemm_problem(A, W, out, M, N, K, A.shape[1], W.shape[1], N, bias_n=bias, resid=resid, ldr=N)
+    ops.gemm_grouped(dtype, GEMM_NT, [p])
+    ref = Ar.double() @ Wr.double().T + bias.cpu().double() + resid.cpu().double()
+    close(out, ref, tol(dtype) if dtype == BPM_F32 else 2e-3, "nt")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_nn_tn_and_splitk(dtype):
+    M, N, K = 300, 140, 200          # dgrad: dx[M,K'] = dy[M,N'] W[N',K']; here generic names
+    A, Ar = to_ct(rnd(M, K, seed=5), dtype)
+    Bm, Br = to_ct(rnd(K, N, seed=6, scale=K ** -0.5), dtype)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_grouped(dtype, GEMM_NN, [ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N)])
+    close(out, Ar.double() @ Br.double(), tol(dtype) if dtype == BPM_F32 else 2e-3, "nn")
+    # TN: C[M,N] = A[K,M]^T B[K,N], contraction over rows, split-K with atomics into zeros
+    Kc = 1000
+    At, Atr = to_ct(rnd(Kc, M, seed=7), dtype)
+    Bt, Btr = to_ct(rnd(Kc, N, seed=8, scale=Kc ** -0.5), dtype)
+    for splitk in (1, 4):
+        out = torch.zeros(M, N, device=DEV)
+        ops.gemm_grouped(dtype, GEMM_TN, [ops.gemm_problem(At, Bt, out, M, N, Kc, At.shape[1], Bt.shape[1], N,
+                                                           flags=F_ATOMIC, splitk=splitk)])
+        close(out, Atr.double().T @ Btr.double(), tol(dtype) if dtype == BPM_F32 else 2e-3, f"tn splitk={splitk}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_epilogues_grouped(dtype):
+    """relu+dropout -> CT (fc1), gate (fc2 dgrad), heads scatter (Q proj), three problems in one launch."""
+    M, N, K = 70, 100, 64
+    B_, H, dh, dhp = 5, 4, 25, 32
+    T_ = M // B_
+    ctt = ops.ct_torch(dtype)
+    A, Ar = to_ct(rnd(M, K, seed=11), dtype)
+    W, Wr = to_ct(rnd(N, K, seed=12, scale=K ** -0.5), dtype)
+    bias = rnd(N, seed=13).to(DEV)
+    gate, gater = to_ct(rnd(M, N, seed=14), dtype)
+    o1 = torch.full((M, pad32(N)), float("nan"), device=DEV).to(ctt)
+    o2 = torch.full((M, N), float("nan"), device=DEV)
+    o3 = torch.zeros(B_, H, T_, dhp, device=DEV, dtype=ctt)
+    p1 = ops.gemm_problem(A, W, o1, M, N, K, A.shape[1], W.shape[1], pad32(N), bias_n=bias, flags=F_RELU,
+                          drop_p=0.3, drop_seed=77, drop_site=5, out_kind=OUT_CT)
+    p2 = ops.gemm_problem(A, W, o2, M, N, K, A.shape[1], W.shape[1], N, gate=gate, ldg=gate.shape[1], gate_scale=1.25)
+    p3 = ops.gemm_problem(A, W, o3, M, N, K, A.shape[1], W.shape[1], 0, bias_n=bias, alpha=0.2, out_kind=OUT_HEADS,
+                          heads=(B_, H, T_, dh, dhp))
+    ops.gemm_grouped(dtype, GEMM_NT, [p1, p2, p3])
+    acc = Ar.double() @ Wr.double().T
+    t = tol(dtype) if dtype == BPM_F32 else 1e-2
+    ref1 = torch.relu(acc + bias.cpu().double()) * drop_mult((M, N), 0.3, 77, 5).double()
+    close(o1[:, :N].float(), ref1, t, "relu+dropout CT")
+    assert (o1[:, N:].float() == 0).all(), "pad columns must be zero"
+    frac = (ref1 == 0).double().mean().item()
+    assert 0.3 < frac < 0.9
+    close(o2, torch.where(gater.double() > 0, acc * 1.25, torch.zeros_like(acc)), t, "gate")
+    ref3 = ((acc + bias.cpu().double()) * 0.2).reshape(T_, B_, H, dh).permute(1, 2, 0, 3)
+    close(o3[..., :dh].float(), ref3, t, "heads")
+    assert (o3[..., dh:].float() == 0).all()
+
+
+# ---------------------------------------------------------------------------
+def attn_ref(q, k, v, off, pmask):
+    """q [B,H,T,dh] (already scaled), k,v [B,H,S,dh]; pmask [B,H,T,S] dropout multipliers."""
+    T_, S_ = q.shape[2], k.shape[2]
+    s = q @ k.transpose(-1, -2)
+    if off > 0:
+        i = torch.arange(T_)[:, None]
+        j = torch.arange(S_)[None, :]
+        s = s.masked_fill((j - i) >= off, float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p * pmask) @ v, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,T,S,dh,masked,pdrop", [(2, 3, 70, 100, 25, True, 0.0), (1, 2, 130, 130, 25, True, 0.2),
+                                                      (2, 2, 100, 70, 6, True, 0.0), (1, 2, 50, 50, 128, True, 0.0),
+                                                      (1, 1, 33, 65, 64, False, 0.1), (1, 2, 2, 200, 25, True, 0.0)])
+def test_attention_fwd_bwd(dtype, B, H, T, S, dh, masked, pdrop):
+    dhp = 32 if dh <= 32 else (64 if dh <= 64 else 128)
+    ctt = ops.ct_torch(dtype)
+    d = H * dh
+    ld = pad32(d)
+
+    def heads(x):        # [B,H,L,dh] cpu -> device CT [B,H,L,dhp], and the CT-rounded values
+        buf = torch.zeros(*x.shape[:3], dhp, dtype=ctt)
+        buf[..., :dh] = x.to(ctt)
+        return buf.to(DEV), buf[..., :dh].double()
+
+    Q, q = heads(rnd(B, H, T, dh, seed=21) * dh ** -0.5)
+    K, k = heads(rnd(B, H, S, dh, seed=22))
+    V, v = heads(rnd(B, H, S, dh, seed=23))
+    dO, do = heads(rnd(B, H, T, dh, seed=24))
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    off = 1 + abs(S - T) if masked else 0
+    pm = drop_mult((B, H, T, S), pdrop, 9, 3).double()
+    o_ref, lse_ref = attn_ref(q, k, v, off, pm)
+    (o_ref * do).sum().backward()
+
+    O = torch.zeros(T * B, ld, device=DEV, dtype=ctt)
+    lse = torch.zeros(B, H, T, device=DEV)
+    delta = torch.zeros(B, H, T, device=DEV)
+    dQ, dK, dV = (torch.zeros(L * B, ld, device=DEV, dtype=ctt) for L in (T, S, S))
+    p = ops.attn_problem(Q, K, V, O, ld, lse, B, H, T, S, dh, dhp, off, dO=dO, delta=delta, dQ=dQ, lddq=ld, dK=dK, lddk=ld,
+                         dV=dV, lddv=ld, dq_scale=1.0, drop_p=pdrop, drop_seed=9, drop_site=3)
+    ops.attn_fwd(dtype, [p])
+    t = 3e-5 if dtype == BPM_F32 else 2e-2
+
+    def rows(x, L):      # row-major [(l*B+b), h*dh+c] -> [B,H,L,dh]
+        return x[:, :d].float().reshape(L, B, H, dh).permute(1, 2, 0, 3)
+
+    close(rows(O, T), o_ref.detach(), t, "O")
+    close(lse, lse_ref.detach(), t, "lse")
+    assert (O[:, d:].float() == 0).all()
+    ops.attn_bwd(dtype, [p])
+    tb = 1e-4 if dtype == BPM_F32 else 4e-2
+    close(rows(dQ, T), q.grad, tb, "dQ")
+    close(rows(dK, S), k.grad, tb, "dK")
+    close(rows(dV, S), v.grad, tb, "dV")
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+def test_pack_rows_and_embed_pos(dtype):
+    B, T, Cn = 3, 7, 35
+    ld = pad32(Cn)
+    src = rnd(B, T, Cn, seed=31)
+    dst = torch.full((T * B, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
+    ops.pack_rows_fwd(dtype, src.to(DEV), dst, B, T, Cn, ld, 0.25, 5, 2)
+    ref = (src * drop_mult((B, T, Cn), 0.25, 5, 2)).permute(1, 0, 2).reshape(T * B, Cn)
+    close(dst[:, :Cn].float(), ref.to(ops.ct_torch(dtype)).float(), 1e-6, "pack fwd")
+    assert (dst[:, Cn:].float() == 0).all()
+    g = rnd(T * B, ld, seed=32).to(DEV)
+    dsrc = torch.full((B, T, Cn), float("nan"), device=DEV)
+    ops.pack_rows_bwd(g, ld, dsrc, B, T, Cn, 0.25, 5, 2)
+    refb = g.cpu()[:, :Cn].reshape(T, B, Cn).permute(1, 0, 2) * drop_mult((B, T, Cn), 0.25, 5, 2)
+    close(dsrc, refb, 1e-6, "pack bwd")
+
+    from oracle import bpmult_cpu as O
+    T2, B2, d = 9, 3, 24
+    x = rnd(T2, B2, d, seed=33)
+    x[2, 1, 0] = 0.0
+    x[-2:] = 0.0
+    table = O.sinusoid_table(T2 + 1, d).to(DEV)
+    out = torch.empty(T2, B2, d, device=DEV)
+    ops.embed_pos_fwd(x.to(DEV), table, out, T2, B2, d, math.sqrt(d), 0.25, 1, 4)
+    ref = (math.sqrt(d) * x + O.pos_embedding(x)) * drop_mult((T2, B2, d), 0.25, 1, 4)
+    close(out, ref, 1e-6, "embed_pos fwd")
+    dy = rnd(T2, B2, d, seed=34)
+    dx = torch.ones(T2, B2, d, device=DEV)
+    ops.embed_pos_bwd(dy.to(DEV), dx, T2, B2, d, math.sqrt(d), 0.25, 1, 4, accumulate=True)
+    close(dx, 1.0 + math.sqrt(d) * dy * drop_mult((T2, B2, d), 0.25, 1, 4), 1e-6, "embed_pos bwd")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("R,d", [(37, 300), (10, 24), (9, 50), (5, 768), (3, 1536)])
+def test_layernorm(dtype, R, d):
+    x = (rnd(R, d, seed=41) * 2 + 0.5).requires_grad_(True)
+    x.data[1] = 0.0                                  # an all-zero (padded) row: LN(0) = beta
+    gamma = (1 + 0.1 * rnd(d, seed=42)).requires_grad_(True)
+    beta = (0.1 * rnd(d, seed=43)).requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5)
+    dy = rnd(R, d, seed=44)
+    (y * dy).sum().backward()
+    ld = pad32(d)
+    out = torch.full((R, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
+    mean, rstd = torch.empty(R, device=DEV), torch.empty(R, device=DEV)
+    xd, gd, bd = x.detach().to(DEV), gamma.detach().to(DEV), beta.detach().to(DEV)
+    ops.ln_fwd(dtype, xd, gd, bd, out, ld, mean, rstd, R, d)
+    close(out[:, :d].float(), y.detach(), 2e-5 if dtype == BPM_F32 else 1e-2, "ln fwd")
+    assert (out[:, d:].float() == 0).all()
+    outf = torch.empty(R, d, device=DEV)
+    ops.ln_fwd(ops.LN_OUT_F32, xd, gd, bd, outf, d, mean, rstd, R, d)
+    close(outf, y.detach(), 2e-5, "ln fwd f32")
+    add = rnd(R, d, seed=45).to(DEV)
+    dx = torch.empty(R, d, device=DEV)
+    dgam, dbet = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ops.ln_bwd(dy.to(DEV), d, xd, mean, rstd, gd, add, dx, dgam, dbet, R, d)
+    close(dx, x.grad + add.cpu(), 1e-4, "ln dx")
+    close(dgam, gamma.grad, 1e-4, "ln dgamma")
+    close(dbet, beta.grad, 1e-4, "ln dbeta")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_rows_cast_and_gmu(dtype):
+    R, Cn = 77, 300
+    ld = pad32(Cn)
+    a, b = rnd(R, Cn, seed=51), rnd(R, Cn, seed=52)
+    dct = torch.full((R, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
+    df = torch.empty(R, Cn, device=DEV)
+    cs = torch.ones(Cn, device=DEV)
+    ops.rows_cast(dtype, a.to(DEV), Cn, R, Cn, b=b.to(DEV), ldb=Cn, dst_ct=dct, ldd=ld, dst_f32=df, ldf=Cn, colsum=cs,
+                  drop_p=0.1, seed=3, site=9)
+    ref = (a + b) * drop_mult((R, Cn), 0.1, 3, 9)
+    close(df, ref, 1e-6, "cast f32")
+    close(dct[:, :Cn].float(), ref.to(ops.ct_torch(dtype)).float(), 1e-6, "cast ct")
+    assert (dct[:, Cn:].float() == 0).all()
+    close(cs, 1.0 + ref.sum(0), 1e-4, "colsum")
+
+    d = 24
+    ts = [rnd(R, d, seed=60 + i).requires_grad_(True) for i in range(5)]
+    a1, a2, ag, x1, x2 = ts
+    z = torch.sigmoid(ag)
+    y = z * torch.tanh(a1) * x1 + (1 - z) * torch.tanh(a2) * x2
+    dout = rnd(R, d, seed=66)
+    (y * dout).sum().backward()
+    dv = [t.detach().to(DEV) for t in ts]
+    out = torch.empty(R, d, device=DEV)
+    ops.gmu2_fwd(*dv, out, R, d)
+    close(out, y.detach(), 1e-5, "gmu fwd")
+    ldg = pad32(d)
+    das = [torch.full((R, ldg), float("nan"), device=DEV).to(ops.ct_torch(dtype)) for _ in range(3)]
+    dx1, dx2 = torch.empty(R, d, device=DEV), torch.empty(R, d, device=DEV)
+    ops.gmu2_bwd(dtype, dout.to(DEV), *dv, *das, ldg, dx1, dx2, R, d)
+    t = 1e-5 if dtype == BPM_F32 else 1e-2
+    for got, ref_, n in zip(das, (a1, a2, ag), ("da1", "da2", "dag")):
+        close(got[:, :d].float(), ref_.grad, t, n)
+        assert (got[:, d:].float() == 0).all()
+    close(dx1, x1.grad, 1e-5, "dx1")
+    close(dx2, x2.grad, 1e-5, "dx2")
