@@ -19,7 +19,7 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
 F_ACCUM, F_RELU, F_ATOMIC = 1, 2, 4
 LN_OUT_F32 = 2
-MAX_GROUP = 12
+MAX_GROUP = 18
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -43,8 +43,8 @@ class GemmProblem(C.Structure):
                 ("bias_n", C.c_void_p), ("bias_m", C.c_void_p),
                 ("resid", C.c_void_p), ("ldr", C.c_int),
                 ("gate", C.c_void_p), ("ldg", C.c_int), ("gate_scale", C.c_float),
-                ("alpha", C.c_float), ("drop_p", C.c_float),
-                ("drop_seed", C.c_uint64), ("drop_site", C.c_uint32),
+                ("alpha", C.c_float), ("drop_p", C.c_float), ("drop_site", C.c_uint32),
+                ("colsum", C.c_void_p),
                 ("flags", C.c_int), ("out_kind", C.c_int), ("splitk", C.c_int),
                 ("heads_B", C.c_int), ("heads_H", C.c_int), ("heads_T", C.c_int),
                 ("heads_dh", C.c_int), ("heads_dhp", C.c_int)]
@@ -59,13 +59,46 @@ class AttnProblem(C.Structure):
                 ("dV", C.c_void_p), ("lddv", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("S", C.c_int),
                 ("dh", C.c_int), ("dhp", C.c_int), ("mask_off", C.c_int),
-                ("dq_scale", C.c_float), ("drop_p", C.c_float),
-                ("drop_seed", C.c_uint64), ("drop_site", C.c_uint32)]
+                ("dq_scale", C.c_float), ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
+
+
+class PackProblem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("g", C.c_void_p), ("ldg", C.c_int), ("dsrc", C.c_void_p),
+                ("B", C.c_int), ("T", C.c_int), ("C", C.c_int), ("ld", C.c_int),
+                ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
-                ("ld", C.c_int), ("blk0", C.c_uint)]
+                ("ld", C.c_int), ("src_ld", C.c_int), ("dst_ld", C.c_int), ("blk0", C.c_uint)]
+
+
+class EmbedProblem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("T", C.c_int), ("B", C.c_int), ("accumulate", C.c_int),
+                ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
+
+
+class LnProblem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("out", C.c_void_p), ("ldo", C.c_int), ("out_f32", C.c_int),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("R", C.c_int),
+                ("dy", C.c_void_p), ("ldy", C.c_int), ("add", C.c_void_p), ("dx", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+class CastProblem(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int), ("a_is_ct", C.c_int),
+                ("b", C.c_void_p), ("ldb", C.c_int),
+                ("dst_ct", C.c_void_p), ("ldd", C.c_int),
+                ("dst_f32", C.c_void_p), ("ldf", C.c_int),
+                ("colsum", C.c_void_p), ("R", C.c_int), ("C", C.c_int),
+                ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
+
+
+class GmuProblem(C.Structure):
+    _fields_ = [("a1", C.c_void_p), ("a2", C.c_void_p), ("ag", C.c_void_p), ("x1", C.c_void_p), ("x2", C.c_void_p),
+                ("out", C.c_void_p), ("dout", C.c_void_p), ("da1", C.c_void_p), ("da2", C.c_void_p), ("dag", C.c_void_p),
+                ("ldg", C.c_int), ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("R", C.c_int)]
 
 
 _P, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
@@ -74,19 +107,19 @@ _P, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
 SIGNATURES = {
     "bpm_version": [],
     "bpm_error_string": [_I],
-    "bpm_gemm_grouped": [_I, _I, C.POINTER(GemmProblem), _I, _P],
-    "bpm_attn_fwd": [_I, C.POINTER(AttnProblem), _I, _P],
-    "bpm_attn_bwd": [_I, C.POINTER(AttnProblem), _I, _P],
-    "bpm_pack_rows_fwd": [_I, _P, _P, _I, _I, _I, _I, _F, _U64, _U32, _P],
-    "bpm_pack_rows_bwd": [_P, _I, _P, _I, _I, _I, _F, _U64, _U32, _P],
+    "bpm_gemm_grouped": [_I, _I, C.POINTER(GemmProblem), _I, _U64, _P],
+    "bpm_attn_fwd": [_I, C.POINTER(AttnProblem), _I, _U64, _P],
+    "bpm_attn_bwd": [_I, C.POINTER(AttnProblem), _I, _U64, _P],
+    "bpm_pack_rows_fwd": [_I, C.POINTER(PackProblem), _I, _U64, _P],
+    "bpm_pack_rows_bwd": [C.POINTER(PackProblem), _I, _U64, _P],
     "bpm_pack_weights": [_I, _P, _I, C.c_uint, _P],
-    "bpm_embed_pos_fwd": [_P, _P, _I, _P, _I, _I, _I, _F, _F, _U64, _U32, _P],
-    "bpm_embed_pos_bwd": [_P, _P, _I, _I, _I, _F, _F, _U64, _U32, _I, _P],
-    "bpm_ln_fwd": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
-    "bpm_ln_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "bpm_rows_cast": [_I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _U32, _P],
-    "bpm_gmu2_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "bpm_gmu2_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
+    "bpm_embed_pos_fwd": [C.POINTER(EmbedProblem), _I, _P, _I, _I, _F, _U64, _P],
+    "bpm_embed_pos_bwd": [C.POINTER(EmbedProblem), _I, _I, _F, _U64, _P],
+    "bpm_ln_fwd": [_I, C.POINTER(LnProblem), _I, _I, _F, _P],
+    "bpm_ln_bwd": [C.POINTER(LnProblem), _I, _I, _P],
+    "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
+    "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
+    "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
 }
 
 _lib = None

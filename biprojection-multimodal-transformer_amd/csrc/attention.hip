@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
     }
 }
 
-int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S, int* total) {
+int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S, uint64_t seed, int* total) {
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
     g.nprob = nprob;
     int blk = 0;
@@ -412,7 +412,7 @@ int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S,
         p.drop.thresh = 0; p.drop.key = 0; p.drop.inv_keep = 1.f;
         if (q.drop_p > 0.f) {
             p.drop.thresh = (uint32_t)(q.drop_p * 16777216.0 + 0.5);
-            p.drop.key = bpm_host_drop_key(q.drop_seed, q.drop_site);
+            p.drop.key = bpm_host_drop_key(seed, q.drop_site);
             p.drop.inv_keep = 1.f / (1.f - q.drop_p);
         }
         p.nblk = ((blocks_over_S ? q.S : q.T) + 63) / 64;
@@ -445,10 +445,10 @@ int dispatch(int which, int dhp, const AGroup& g, int total, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob, void* stream) {
+extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
     AGroup g;
     int total = 0;
-    int rc = fill(g, probs, nprob, 0, &total);
+    int rc = fill(g, probs, nprob, 0, seed, &total);
     if (rc) return rc;
     for (int i = 0; i < nprob; ++i)
         if (!probs[i].Q || !probs[i].K || !probs[i].V || !probs[i].O || !probs[i].lse) return BPM_ERR_ARG;
@@ -457,10 +457,10 @@ extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob,
 }
 
 // dQ first (it also produces delta), then dK/dV on the same stream.
-extern "C" int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs, int nprob, void* stream) {
+extern "C" int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
     AGroup g;
     int total = 0;
-    int rc = fill(g, probs, nprob, 0, &total);
+    int rc = fill(g, probs, nprob, 0, seed, &total);
     if (rc) return rc;
     for (int i = 0; i < nprob; ++i) {
         const bpm_attn_problem& q = probs[i];
@@ -469,7 +469,7 @@ extern "C" int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs, int nprob,
     hipStream_t s = (hipStream_t)stream;
     rc = dtype == BPM_BF16 ? dispatch<bf16_t>(1, probs[0].dhp, g, total, s) : dispatch<float>(1, probs[0].dhp, g, total, s);
     if (rc) return rc;
-    rc = fill(g, probs, nprob, 1, &total);
+    rc = fill(g, probs, nprob, 1, seed, &total);
     if (rc) return rc;
     return dtype == BPM_BF16 ? dispatch<bf16_t>(2, probs[0].dhp, g, total, s) : dispatch<float>(2, probs[0].dhp, g, total, s);
 }

@@ -49,6 +49,7 @@ struct Prob {
     const char* gate; int ldg; float gate_scale;
     float alpha;
     DropCfg drop;
+    float* colsum;
     int flags;
     int out_kind;
     int hB, hH, hT, hdh, hdhp;
@@ -220,6 +221,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
     const bool accum = (P.flags & BPM_GEMM_ACCUM) != 0;
     const bool relu = (P.flags & BPM_GEMM_RELU) != 0;
     if (kt_lo >= kt_hi && !lead) return;
+    float csum[TN][4];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) csum[a][q] = 0.f;
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         const int m = m0 + wm * (BM / WM) + 16 * b + r;
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
                         x = gv > 0.f ? x * P.gate_scale : 0.f;
                     }
                     x *= bpm_drop_mult(P.drop, (uint32_t)m * (uint32_t)P.N + (uint32_t)n);
+                    csum[a][q] += x;
                     if (P.resid && lead) x += P.resid[(size_t)m * P.ldr + n];
                 } else {
                     x = 0.f;
@@ -274,6 +281,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
             }
         }
     }
+    if (P.colsum) {   // uniform per block: every lane takes part in the shuffles
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = csum[a][q];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                const int n = n0 + wn * (BN / WN) + 16 * a + 4 * g + q;
+                if (r == 0 && n < P.N) atomicAdd(P.colsum + n, v);
+            }
+    }
 }
 
 template <typename CT>
@@ -291,7 +312,7 @@ int launch(int variant, const Group& g, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs, int nprob, void* stream) {
+extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs, int nprob, uint64_t seed, void* stream) {
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
     const int sz = dtype == BPM_BF16 ? 2 : 4;
     Group g;
@@ -314,9 +335,10 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         p.drop.thresh = 0; p.drop.key = 0; p.drop.inv_keep = 1.f;
         if (q.drop_p > 0.f) {
             p.drop.thresh = (uint32_t)(q.drop_p * 16777216.0 + 0.5);
-            p.drop.key = bpm_host_drop_key(q.drop_seed, q.drop_site);
+            p.drop.key = bpm_host_drop_key(seed, q.drop_site);
             p.drop.inv_keep = 1.f / (1.f - q.drop_p);
         }
+        p.colsum = q.colsum;
         p.flags = q.flags; p.out_kind = q.out_kind;
         p.hB = q.heads_B; p.hH = q.heads_H; p.hT = q.heads_T; p.hdh = q.heads_dh; p.hdhp = q.heads_dhp;
         if (q.out_kind == BPM_OUT_HEADS && (q.heads_B < 1 || q.heads_dh < 1 || q.heads_H * q.heads_dh != q.N)) return BPM_ERR_ARG;

@@ -4,6 +4,11 @@
 // whose roofline is HBM bandwidth; rows are [(t*B + b), d] fp32 on the
 // residual stream and CT (f32 / bf16, leading dim padded to 32 with zeros)
 // where the consumer is an MFMA GEMM.
+//
+// Every entry point is GROUPED: one launch serves up to BPM_MAX_GROUP
+// independent problems (the encoders of one level run in lock-step), passed
+// by value in the kernel-argument segment; a block finds its problem from a
+// prefix table of block counts.
 #include "bpm_common.h"
 #include "../../include/bpmult_hip.h"
 
@@ -24,11 +29,29 @@ inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
     return d;
 }
 
-inline int grid_for(size_t n, int per_block) {
+inline unsigned blocks_for(size_t n, int per_block, unsigned cap) {
     size_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
-    if (g > 65535u * 16u) g = 65535u * 16u;
-    return (int)g;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+template <typename P> struct Grp {
+    int n;
+    unsigned blk0[BPM_MAX_GROUP + 1];   // prefix of block counts
+    P p[BPM_MAX_GROUP];
+};
+
+// block -> (problem index, block within problem, blocks of that problem)
+template <typename P>
+BPM_DEV const P& pick(const Grp<P>& g, unsigned& bid, unsigned& nblk) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.n; ++i)
+        if (bid >= g.blk0[i]) pi = i;
+    nblk = g.blk0[pi + 1] - g.blk0[pi];
+    bid -= g.blk0[pi];
+    return g.p[pi];
 }
 
 // ---------------------------------------------------------------------------
@@ -36,40 +59,45 @@ inline int grid_for(size_t n, int per_block) {
 // (reference mmtr.py:741-753: dropout on the raw text features, transpose,
 //  permute(2,0,1); the permutation is done here on the read side)
 // ---------------------------------------------------------------------------
+struct PackP { const float* src; void* dst; float* dsrc; const float* g; int ldg; int B, T, C, ld; DropCfg drop; };
+
 template <typename CT>
-__global__ void pack_rows_fwd_kernel(const float* __restrict__ src, void* dst, int B, int T, int C, int ld, DropCfg drop) {
-    const size_t total = (size_t)T * B * ld;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
-        const int c = (int)(i % ld);
-        const size_t row = i / ld;
-        const int b = (int)(row % B), t = (int)(row / B);
+__global__ void pack_rows_fwd_kernel(const Grp<PackP> grp) {
+    unsigned bid = blockIdx.x, nblk;
+    const PackP& P = pick(grp, bid, nblk);
+    const size_t total = (size_t)P.T * P.B * P.ld;
+    for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
+        const int c = (int)(i % P.ld);
+        const size_t row = i / P.ld;
+        const int b = (int)(row % P.B), t = (int)(row / P.B);
         float v = 0.f;
-        if (c < C) {
-            const size_t si = ((size_t)b * T + t) * C + c;
-            v = src[si] * bpm_drop_mult(drop, (uint32_t)si);
+        if (c < P.C) {
+            const size_t si = ((size_t)b * P.T + t) * P.C + c;
+            v = P.src[si] * bpm_drop_mult(P.drop, (uint32_t)si);
         }
-        put<CT>(dst, i, v);
+        put<CT>(P.dst, i, v);
     }
 }
 
 // d(src)[b,t,c] = drop_mult * g[(t*B+b), c]   (g fp32, leading dim ldg)
-__global__ void pack_rows_bwd_kernel(const float* __restrict__ g, int ldg, float* dsrc, int B, int T, int C, DropCfg drop) {
-    const size_t total = (size_t)T * B * C;
-    for (size_t si = (size_t)blockIdx.x * NT + threadIdx.x; si < total; si += (size_t)gridDim.x * NT) {
-        const int c = (int)(si % C);
-        const size_t bt = si / C;
-        const int t = (int)(bt % T), b = (int)(bt / T);
-        dsrc[si] = g[((size_t)t * B + b) * ldg + c] * bpm_drop_mult(drop, (uint32_t)si);
+__global__ void pack_rows_bwd_kernel(const Grp<PackP> grp) {
+    unsigned bid = blockIdx.x, nblk;
+    const PackP& P = pick(grp, bid, nblk);
+    const size_t total = (size_t)P.T * P.B * P.C;
+    for (size_t si = (size_t)bid * NT + threadIdx.x; si < total; si += (size_t)nblk * NT) {
+        const int c = (int)(si % P.C);
+        const size_t bt = si / P.C;
+        const int t = (int)(bt % P.T), b = (int)(bt / P.T);
+        P.dsrc[si] = P.g[((size_t)t * P.B + b) * P.ldg + c] * bpm_drop_mult(P.drop, (uint32_t)si);
     }
 }
 
 // ---------------------------------------------------------------------------
-// weight shadows: every fp32 master [rows, cols] -> CT [rows, ld] (zero pad),
-// one launch over a device-resident table
+// weight shadows: every fp32 master [rows, cols] (row stride src_ld) -> CT
+// [rows, ld] (zero pad), one launch over a device-resident table
 // ---------------------------------------------------------------------------
 template <typename CT>
 __global__ void pack_weights_kernel(const bpm_pack_desc* __restrict__ tab, int ndesc) {
-    // block -> descriptor by binary search on blk0
     int lo = 0, hi = ndesc - 1;
     const unsigned bid = blockIdx.x;
     while (lo < hi) {
@@ -86,48 +114,60 @@ __global__ void pack_weights_kernel(const bpm_pack_desc* __restrict__ tab, int n
         if (i >= total) break;
         const int c = (int)(i % d.ld);
         const size_t r = i / d.ld;
-        put<CT>(d.dst, i, c < d.cols ? src[r * d.cols + c] : 0.f);
+        put<CT>(d.dst, r * d.dst_ld + c, c < d.cols ? src[r * d.src_ld + c] : 0.f);
     }
 }
 
 // ---------------------------------------------------------------------------
 // embedding prologue (reference transformer.py:66-79, position_embedding.py:62-76)
 //   out = dropout(scale * x + table[pos]),  pos = t+1 if x[t,b,0] != 0 else 0
+// backward: dx (+)= scale * drop_mult * dy   (the positional term is detached)
 // ---------------------------------------------------------------------------
-__global__ void embed_pos_fwd_kernel(const float* __restrict__ x, const float* __restrict__ table, float* out,
-                                     int T, int B, int d, float scale, DropCfg drop) {
-    const size_t total = (size_t)T * B * d;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+struct EmbP { const float* x; float* out; int T, B; int accumulate; DropCfg drop; };
+
+__global__ void embed_pos_fwd_kernel(const Grp<EmbP> grp, const float* __restrict__ table, int d, float scale) {
+    unsigned bid = blockIdx.x, nblk;
+    const EmbP& P = pick(grp, bid, nblk);
+    const size_t total = (size_t)P.T * P.B * d;
+    for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
         const int c = (int)(i % d);
         const size_t row = i / d;
-        const int t = (int)(row / B);
-        const int pos = (x[row * d] != 0.f) ? t + 1 : 0;
-        out[i] = (scale * x[i] + table[(size_t)pos * d + c]) * bpm_drop_mult(drop, (uint32_t)i);
+        const int t = (int)(row / P.B);
+        const int pos = (P.x[row * d] != 0.f) ? t + 1 : 0;
+        P.out[i] = (scale * P.x[i] + table[(size_t)pos * d + c]) * bpm_drop_mult(P.drop, (uint32_t)i);
     }
 }
 
-// dx (+)= scale * drop_mult * dy     (the positional term is detached)
-__global__ void embed_pos_bwd_kernel(const float* __restrict__ dy, float* dx, size_t total, float scale, DropCfg drop, int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
-        const float v = scale * dy[i] * bpm_drop_mult(drop, (uint32_t)i);
-        dx[i] = accumulate ? dx[i] + v : v;
+__global__ void embed_pos_bwd_kernel(const Grp<EmbP> grp, int d, float scale) {
+    unsigned bid = blockIdx.x, nblk;
+    const EmbP& P = pick(grp, bid, nblk);      // x = dy, out = dx
+    const size_t total = (size_t)P.T * P.B * d;
+    for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
+        const float v = scale * P.x[i] * bpm_drop_mult(P.drop, (uint32_t)i);
+        P.out[i] = P.accumulate ? P.out[i] + v : v;
     }
 }
 
 // ---------------------------------------------------------------------------
 // LayerNorm, eps inside the sqrt, biased variance (nn.LayerNorm).  One wave
-// per row, row held in registers (d <= 64*MAXE).
+// per row, row held in registers (NE = ceil(span/64) elements per lane).
 // ---------------------------------------------------------------------------
 constexpr int MAXE = 32;
 
-template <typename CT, bool F32OUT, int NE>
-__global__ __launch_bounds__(NT) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, void* out, int ldo,
-                                                    float* mean, float* rstd, int R, int d, float eps) {
+struct LnP {
+    const float* x; const float* gamma; const float* beta; void* out; int ldo; int out_f32;
+    float* mean; float* rstd; int R;
+    const float* dy; int ldy; const float* add; float* dx; float* dgamma; float* dbeta;
+};
+
+template <typename CT, int NE>
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(const Grp<LnP> grp, int d, float eps) {
+    unsigned bid = blockIdx.x, nblk;
+    const LnP& P = pick(grp, bid, nblk);
     const int lane = threadIdx.x & 63;
     const int wpb = NT / 64;
-    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < R; row += gridDim.x * wpb) {
-        const float* xr = x + (size_t)row * d;
+    for (int row = bid * wpb + (threadIdx.x >> 6); row < P.R; row += nblk * wpb) {
+        const float* xr = P.x + (size_t)row * d;
         float v[NE];
         float s = 0.f;
 #pragma unroll
@@ -145,16 +185,16 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const float* __restrict__ x,
             q += t * t;
         }
         const float rs = rsqrtf(wave_sum(q) / d + eps);
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        if (lane == 0) { P.mean[row] = mu; P.rstd[row] = rs; }
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int c = lane + 64 * e;
             if (c < d) {
-                const float y = (v[e] - mu) * rs * gamma[c] + beta[c];
-                if (F32OUT) ((float*)out)[(size_t)row * ldo + c] = y;
-                else put<CT>(out, (size_t)row * ldo + c, y);
-            } else if (!F32OUT && c < ldo) {
-                put<CT>(out, (size_t)row * ldo + c, 0.f);
+                const float y = (v[e] - mu) * rs * P.gamma[c] + P.beta[c];
+                if (P.out_f32) ((float*)P.out)[(size_t)row * P.ldo + c] = y;
+                else put<CT>(P.out, (size_t)row * P.ldo + c, y);
+            } else if (!P.out_f32 && c < P.ldo) {
+                put<CT>(P.out, (size_t)row * P.ldo + c, 0.f);
             }
         }
     }
@@ -163,20 +203,19 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const float* __restrict__ x,
 // dx = add + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // dgamma += sum_rows dy * xhat,  dbeta += sum_rows dy   (atomics, one per column per block)
 template <int NE>
-__global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
-                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    const float* __restrict__ gamma, const float* add, float* dx,
-                                                    float* dgamma, float* dbeta, int R, int d) {
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const Grp<LnP> grp, int d) {
     __shared__ float red[2][NT / 64][512];   // 512 columns per pass
+    unsigned bid = blockIdx.x, nblk;
+    const LnP& P = pick(grp, bid, nblk);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wpb = NT / 64;
     float ag[NE], ab[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
-    for (int row = blockIdx.x * wpb + wv; row < R; row += gridDim.x * wpb) {
-        const float mu = mean[row], rs = rstd[row];
-        const float* xr = x + (size_t)row * d;
-        const float* gr = dy + (size_t)row * ldy;
+    for (int row = bid * wpb + wv; row < P.R; row += nblk * wpb) {
+        const float mu = P.mean[row], rs = P.rstd[row];
+        const float* xr = P.x + (size_t)row * d;
+        const float* gr = P.dy + (size_t)row * P.ldy;
         float xh[NE], gg[NE];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -185,7 +224,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
             if (c < d) {
                 const float dyv = gr[c];
                 xh[e] = (xr[c] - mu) * rs;
-                gg[e] = dyv * gamma[c];
+                gg[e] = dyv * P.gamma[c];
                 ag[e] += dyv * xh[e];
                 ab[e] += dyv;
                 s1 += gg[e];
@@ -200,12 +239,11 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
             if (c < d) {
                 const float v = rs * (gg[e] - s1 - xh[e] * s2);
                 const size_t i = (size_t)row * d + c;
-                dx[i] = add ? add[i] + v : v;
+                P.dx[i] = P.add ? P.add[i] + v : v;
             }
         }
     }
-    if (!dgamma) return;
-    // reduce the 4 waves' partial column sums through LDS, 8 register slots (512 columns) at a time
+    if (!P.dgamma) return;     // uniform per block
 #pragma unroll
     for (int e0 = 0; e0 < NE; e0 += 8) {
         __syncthreads();
@@ -221,41 +259,49 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
                 float sg = 0.f, sb = 0.f;
 #pragma unroll
                 for (int w = 0; w < NT / 64; ++w) { sg += red[0][w][i]; sb += red[1][w][i]; }
-                atomicAdd(dgamma + c, sg);
-                atomicAdd(dbeta + c, sb);
+                atomicAdd(P.dgamma + c, sg);
+                atomicAdd(P.dbeta + c, sb);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// rows_cast: y = (a [+ b]) * drop_mult ; written as CT (padded) and/or fp32;
-// optional column sums (bias gradient) by atomics.
+// rows_cast: y = (a [+ b]) * drop_mult ; a is fp32 or CT; written as CT
+// (padded) and/or fp32; optional column sums (bias gradient) by atomics.
+// Block = 32 rows x 256 columns.
 // ---------------------------------------------------------------------------
 constexpr int CAST_ROWS = 32;
 
+struct CastP {
+    const void* a; int lda; int a_is_ct; const float* b; int ldb;
+    void* dct; int ldd; float* df32; int ldf; float* colsum;
+    int R, C; int cblk;   // column blocks
+    DropCfg drop;
+};
+
 template <typename CT>
-__global__ __launch_bounds__(NT) void rows_cast_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
-                                                       void* dct, int ldd, float* df32, int ldf, float* colsum,
-                                                       int R, int C, DropCfg drop) {
-    const int c = blockIdx.y * NT + threadIdx.x;
-    const int r0 = blockIdx.x * CAST_ROWS;
-    const int r1 = min(R, r0 + CAST_ROWS);
-    const int cmax = dct ? ldd : C;
+__global__ __launch_bounds__(NT) void rows_cast_kernel(const Grp<CastP> grp) {
+    unsigned bid = blockIdx.x, nblk;
+    const CastP& P = pick(grp, bid, nblk);
+    const int c = (bid % P.cblk) * NT + threadIdx.x;
+    const int r0 = (bid / P.cblk) * CAST_ROWS;
+    const int r1 = min(P.R, r0 + CAST_ROWS);
+    const int cmax = P.dct ? P.ldd : P.C;
     if (c >= cmax) return;
     float s = 0.f;
     for (int r = r0; r < r1; ++r) {
         float v = 0.f;
-        if (c < C) {
-            v = a[(size_t)r * lda + c];
-            if (b) v += b[(size_t)r * ldb + c];
-            v *= bpm_drop_mult(drop, (uint32_t)r * (uint32_t)C + (uint32_t)c);
-            if (df32) df32[(size_t)r * ldf + c] = v;
+        if (c < P.C) {
+            v = P.a_is_ct ? Tr<CT>::to_f(((const CT*)P.a)[(size_t)r * P.lda + c]) : ((const float*)P.a)[(size_t)r * P.lda + c];
+            if (P.b) v += P.b[(size_t)r * P.ldb + c];
+            v *= bpm_drop_mult(P.drop, (uint32_t)r * (uint32_t)P.C + (uint32_t)c);
+            if (P.df32) P.df32[(size_t)r * P.ldf + c] = v;
             s += v;
         }
-        if (dct) put<CT>(dct, (size_t)r * ldd + c, v);
+        if (P.dct) put<CT>(P.dct, (size_t)r * P.ldd + c, v);
     }
-    if (colsum && c < C) atomicAdd(colsum + c, s);
+    if (P.colsum && c < P.C) atomicAdd(P.colsum + c, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -263,180 +309,247 @@ __global__ __launch_bounds__(NT) void rows_cast_kernel(const float* __restrict__
 //   out = z*tanh(a1)*x1 + (1-z)*tanh(a2)*x2,  z = sigmoid(ag)
 // a1,a2,ag are the three bias-free linear maps produced by the GEMM kernel.
 // ---------------------------------------------------------------------------
+struct GmuP {
+    const float* a1; const float* a2; const float* ag; const float* x1; const float* x2; float* out;
+    const float* dout; void* da1; void* da2; void* dag; int ldg; float* dx1; float* dx2; int R;
+};
+
 BPM_DEV float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
-__global__ void gmu2_fwd_kernel(const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ ag,
-                                const float* __restrict__ x1, const float* __restrict__ x2, float* out, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
-        const float z = sigmoidf_(ag[i]);
-        out[i] = z * tanhf(a1[i]) * x1[i] + (1.f - z) * tanhf(a2[i]) * x2[i];
+__global__ void gmu2_fwd_kernel(const Grp<GmuP> grp, int d) {
+    unsigned bid = blockIdx.x, nblk;
+    const GmuP& P = pick(grp, bid, nblk);
+    const size_t total = (size_t)P.R * d;
+    for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
+        const float z = sigmoidf_(P.ag[i]);
+        P.out[i] = z * tanhf(P.a1[i]) * P.x1[i] + (1.f - z) * tanhf(P.a2[i]) * P.x2[i];
     }
 }
 
 // da1, da2, dag -> CT [R, ldg] (GEMM operands, pad zeroed); dx1, dx2 (direct terms) -> fp32 [R, d]
 template <typename CT>
-__global__ void gmu2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a1, const float* __restrict__ a2,
-                                const float* __restrict__ ag, const float* __restrict__ x1, const float* __restrict__ x2,
-                                void* da1, void* da2, void* dag, int ldg, float* dx1, float* dx2, int R, int d) {
-    const size_t total = (size_t)R * ldg;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
-        const int c = (int)(i % ldg);
-        const size_t r = i / ldg;
+__global__ void gmu2_bwd_kernel(const Grp<GmuP> grp, int d) {
+    unsigned bid = blockIdx.x, nblk;
+    const GmuP& P = pick(grp, bid, nblk);
+    const size_t total = (size_t)P.R * P.ldg;
+    for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
+        const int c = (int)(i % P.ldg);
+        const size_t r = i / P.ldg;
         float g1 = 0.f, g2 = 0.f, gz = 0.f;
         if (c < d) {
             const size_t k = r * d + c;
-            const float go = dout[k];
-            const float z = sigmoidf_(ag[k]);
-            const float h1 = tanhf(a1[k]), h2 = tanhf(a2[k]);
-            const float u1 = x1[k], u2 = x2[k];
+            const float go = P.dout[k];
+            const float z = sigmoidf_(P.ag[k]);
+            const float h1 = tanhf(P.a1[k]), h2 = tanhf(P.a2[k]);
+            const float u1 = P.x1[k], u2 = P.x2[k];
             g1 = go * z * u1 * (1.f - h1 * h1);
             g2 = go * (1.f - z) * u2 * (1.f - h2 * h2);
             gz = go * (h1 * u1 - h2 * u2) * z * (1.f - z);
-            dx1[k] = go * z * h1;
-            dx2[k] = go * (1.f - z) * h2;
+            P.dx1[k] = go * z * h1;
+            P.dx2[k] = go * (1.f - z) * h2;
         }
-        put<CT>(da1, i, g1);
-        put<CT>(da2, i, g2);
-        put<CT>(dag, i, gz);
+        put<CT>(P.da1, i, g1);
+        put<CT>(P.da2, i, g2);
+        put<CT>(P.dag, i, gz);
     }
 }
 
+constexpr unsigned CAP = 2048;   // blocks per problem for grid-stride kernels
+
+template <typename P> inline bool grp_ok(int n) { return n >= 1 && n <= BPM_MAX_GROUP; }
+
 }  // namespace
 
-#define BPM_DISPATCH_CT(dtype, EXPR_F32, EXPR_BF16)   \
-    do {                                              \
-        if ((dtype) == BPM_BF16) { EXPR_BF16; }       \
-        else { EXPR_F32; }                            \
+#define BPM_DISPATCH_CT(dtype, KERNEL, ...)                                                     \
+    do {                                                                                        \
+        if ((dtype) == BPM_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, __VA_ARGS__);               \
+        else hipLaunchKernelGGL(KERNEL<float>, __VA_ARGS__);                                    \
     } while (0)
 
-extern "C" int bpm_pack_rows_fwd(int dtype, const float* src, void* dst, int B, int T, int C, int ld,
-                                 float drop_p, uint64_t seed, uint32_t site, void* stream) {
-    if (!src || !dst || B < 1 || T < 1 || C < 1 || ld < C) return BPM_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const DropCfg dr = make_drop(drop_p, seed, site);
-    const int grid = grid_for((size_t)T * B * ld, NT * 4);
-    BPM_DISPATCH_CT(dtype,
-        hipLaunchKernelGGL(pack_rows_fwd_kernel<float>, dim3(grid), dim3(NT), 0, s, src, dst, B, T, C, ld, dr),
-        hipLaunchKernelGGL(pack_rows_fwd_kernel<bf16_t>, dim3(grid), dim3(NT), 0, s, src, dst, B, T, C, ld, dr));
+extern "C" int bpm_pack_rows_fwd(int dtype, const bpm_pack_problem* q, int n, uint64_t seed, void* stream) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
+    Grp<PackP> g;
+    g.n = n; g.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!q[i].src || !q[i].dst || q[i].B < 1 || q[i].T < 1 || q[i].C < 1 || q[i].ld < q[i].C) return BPM_ERR_ARG;
+        PackP& p = g.p[i];
+        p.src = q[i].src; p.dst = q[i].dst; p.dsrc = nullptr; p.g = nullptr; p.ldg = 0;
+        p.B = q[i].B; p.T = q[i].T; p.C = q[i].C; p.ld = q[i].ld;
+        p.drop = make_drop(q[i].drop_p, seed, q[i].drop_site);
+        g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)p.T * p.B * p.ld, NT * 4, CAP);
+    }
+    BPM_DISPATCH_CT(dtype, pack_rows_fwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
     BPM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int bpm_pack_rows_bwd(const float* g, int ldg, float* dsrc, int B, int T, int C,
-                                 float drop_p, uint64_t seed, uint32_t site, void* stream) {
-    if (!g || !dsrc || B < 1 || T < 1 || C < 1 || ldg < C) return BPM_ERR_ARG;
-    const DropCfg dr = make_drop(drop_p, seed, site);
-    hipLaunchKernelGGL(pack_rows_bwd_kernel, dim3(grid_for((size_t)T * B * C, NT * 4)), dim3(NT), 0, (hipStream_t)stream,
-                       g, ldg, dsrc, B, T, C, dr);
+extern "C" int bpm_pack_rows_bwd(const bpm_pack_problem* q, int n, uint64_t seed, void* stream) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
+    Grp<PackP> g;
+    g.n = n; g.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!q[i].g || !q[i].dsrc || q[i].B < 1 || q[i].T < 1 || q[i].C < 1 || q[i].ldg < q[i].C) return BPM_ERR_ARG;
+        PackP& p = g.p[i];
+        p.src = nullptr; p.dst = nullptr; p.dsrc = q[i].dsrc; p.g = q[i].g; p.ldg = q[i].ldg;
+        p.B = q[i].B; p.T = q[i].T; p.C = q[i].C; p.ld = 0;
+        p.drop = make_drop(q[i].drop_p, seed, q[i].drop_site);
+        g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)p.T * p.B * p.C, NT * 4, CAP);
+    }
+    hipLaunchKernelGGL(pack_rows_bwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
     BPM_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int bpm_pack_weights(int dtype, const bpm_pack_desc* table_dev, int ndesc, unsigned total_blocks, void* stream) {
     if (!table_dev || ndesc < 1 || total_blocks < 1) return BPM_ERR_ARG;
+    BPM_DISPATCH_CT(dtype, pack_weights_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, ndesc);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+static int fill_embed(Grp<EmbP>& g, const bpm_embed_problem* q, int n, int d, uint64_t seed) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP || d < 1) return BPM_ERR_ARG;
+    g.n = n; g.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!q[i].x || !q[i].out || q[i].T < 1 || q[i].B < 1) return BPM_ERR_ARG;
+        EmbP& p = g.p[i];
+        p.x = q[i].x; p.out = q[i].out; p.T = q[i].T; p.B = q[i].B; p.accumulate = q[i].accumulate;
+        p.drop = make_drop(q[i].drop_p, seed, q[i].drop_site);
+        g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)p.T * p.B * d, NT * 4, CAP);
+    }
+    return 0;
+}
+
+extern "C" int bpm_embed_pos_fwd(const bpm_embed_problem* q, int n, const float* table, int table_rows, int d,
+                                 float scale, uint64_t seed, void* stream) {
+    Grp<EmbP> g;
+    int rc = fill_embed(g, q, n, d, seed);
+    if (rc) return rc;
+    if (!table) return BPM_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (table_rows < q[i].T + 1) return BPM_ERR_ARG;
+    hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, table, d, scale);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bpm_embed_pos_bwd(const bpm_embed_problem* q, int n, int d, float scale, uint64_t seed, void* stream) {
+    Grp<EmbP> g;
+    int rc = fill_embed(g, q, n, d, seed);
+    if (rc) return rc;
+    hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, d, scale);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+static int fill_ln(Grp<LnP>& g, const bpm_ln_problem* q, int n, int d, bool bwd, int* span) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP || d < 1 || d > 64 * MAXE) return BPM_ERR_ARG;
+    g.n = n; g.blk0[0] = 0;
+    *span = d;
+    for (int i = 0; i < n; ++i) {
+        const bpm_ln_problem& s = q[i];
+        LnP& p = g.p[i];
+        if (!s.x || !s.gamma || !s.mean || !s.rstd || s.R < 1) return BPM_ERR_ARG;
+        if (bwd) {
+            if (!s.dy || !s.dx || s.ldy < d || ((s.dgamma == nullptr) != (s.dbeta == nullptr))) return BPM_ERR_ARG;
+        } else {
+            if (!s.beta || !s.out || s.ldo < d || s.ldo > 64 * MAXE) return BPM_ERR_ARG;
+            if (!s.out_f32 && s.ldo > *span) *span = s.ldo;
+        }
+        p.x = s.x; p.gamma = s.gamma; p.beta = s.beta; p.out = s.out; p.ldo = s.ldo; p.out_f32 = s.out_f32;
+        p.mean = s.mean; p.rstd = s.rstd; p.R = s.R;
+        p.dy = s.dy; p.ldy = s.ldy; p.add = s.add; p.dx = s.dx; p.dgamma = s.dgamma; p.dbeta = s.dbeta;
+        g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)s.R, 4, bwd ? 256 : 4096);
+    }
+    return 0;
+}
+
+extern "C" int bpm_ln_fwd(int dtype, const bpm_ln_problem* q, int n, int d, float eps, void* stream) {
+    Grp<LnP> g;
+    int span;
+    int rc = fill_ln(g, q, n, d, false, &span);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    BPM_DISPATCH_CT(dtype,
-        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(total_blocks), dim3(NT), 0, s, table_dev, ndesc),
-        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(total_blocks), dim3(NT), 0, s, table_dev, ndesc));
-    BPM_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int bpm_embed_pos_fwd(const float* x, const float* table, int table_rows, float* out, int T, int B, int d,
-                                 float scale, float drop_p, uint64_t seed, uint32_t site, void* stream) {
-    if (!x || !table || !out || T < 1 || B < 1 || d < 1 || table_rows < T + 1) return BPM_ERR_ARG;
-    const DropCfg dr = make_drop(drop_p, seed, site);
-    hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3(grid_for((size_t)T * B * d, NT * 4)), dim3(NT), 0, (hipStream_t)stream,
-                       x, table, out, T, B, d, scale, dr);
-    BPM_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int bpm_embed_pos_bwd(const float* dy, float* dx, int T, int B, int d, float scale, float drop_p,
-                                 uint64_t seed, uint32_t site, int accumulate, void* stream) {
-    if (!dy || !dx || T < 1 || B < 1 || d < 1) return BPM_ERR_ARG;
-    const DropCfg dr = make_drop(drop_p, seed, site);
-    const size_t total = (size_t)T * B * d;
-    hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(grid_for(total, NT * 4)), dim3(NT), 0, (hipStream_t)stream,
-                       dy, dx, total, scale, dr, accumulate);
-    BPM_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int bpm_ln_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* out, int ldo,
-                          float* mean, float* rstd, int R, int d, float eps, void* stream) {
-    if (!x || !gamma || !beta || !out || !mean || !rstd || R < 1 || d < 1 || d > 64 * MAXE || ldo < d || ldo > 64 * MAXE) return BPM_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const int grid = min(4096, (R + 3) / 4);
-    // the padded row (ldo columns for CT outputs) must fit the lane-strided register tile
-    const int span = out_dtype == BPM_OUT_LN_F32 ? d : ldo;
-#define BPM_LN_FWD(NE)                                                                                                              \
-    if (span <= 64 * NE) {                                                                                                          \
-        if (out_dtype == BPM_OUT_LN_F32)                                                                                            \
-            hipLaunchKernelGGL((ln_fwd_kernel<float, true, NE>), dim3(grid), dim3(NT), 0, s, x, gamma, beta, out, ldo, mean, rstd, R, d, eps); \
-        else if (out_dtype == BPM_BF16)                                                                                             \
-            hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, false, NE>), dim3(grid), dim3(NT), 0, s, x, gamma, beta, out, ldo, mean, rstd, R, d, eps); \
-        else                                                                                                                        \
-            hipLaunchKernelGGL((ln_fwd_kernel<float, false, NE>), dim3(grid), dim3(NT), 0, s, x, gamma, beta, out, ldo, mean, rstd, R, d, eps); \
-        BPM_CHECK_LAUNCH();                                                                                                         \
-        return 0;                                                                                                                   \
+#define BPM_LN_FWD(NE)                                                                            \
+    if (span <= 64 * NE) {                                                                        \
+        if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NE>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, eps); \
+        else hipLaunchKernelGGL((ln_fwd_kernel<float, NE>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, eps);                    \
+        BPM_CHECK_LAUNCH();                                                                       \
+        return 0;                                                                                 \
     }
     BPM_LN_FWD(1) BPM_LN_FWD(2) BPM_LN_FWD(5) BPM_LN_FWD(8) BPM_LN_FWD(12) BPM_LN_FWD(16) BPM_LN_FWD(24) BPM_LN_FWD(32)
 #undef BPM_LN_FWD
     return BPM_ERR_ARG;
 }
 
-extern "C" int bpm_ln_bwd(const float* dy, int ldy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                          const float* add, float* dx, float* dgamma, float* dbeta, int R, int d, void* stream) {
-    if (!dy || !x || !mean || !rstd || !gamma || !dx || R < 1 || d < 1 || d > 64 * MAXE || ldy < d) return BPM_ERR_ARG;
-    if ((dgamma == nullptr) != (dbeta == nullptr)) return BPM_ERR_ARG;
-    const int grid = min(256, (R + 3) / 4);
-#define BPM_LN_BWD(NE)                                                                                                   \
-    if (d <= 64 * NE) {                                                                                                  \
-        hipLaunchKernelGGL(ln_bwd_kernel<NE>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, dy, ldy, x, mean, rstd, gamma, \
-                           add, dx, dgamma, dbeta, R, d);                                                                \
-        BPM_CHECK_LAUNCH();                                                                                              \
-        return 0;                                                                                                        \
+extern "C" int bpm_ln_bwd(const bpm_ln_problem* q, int n, int d, void* stream) {
+    Grp<LnP> g;
+    int span;
+    int rc = fill_ln(g, q, n, d, true, &span);
+    if (rc) return rc;
+#define BPM_LN_BWD(NE)                                                                                        \
+    if (d <= 64 * NE) {                                                                                       \
+        hipLaunchKernelGGL(ln_bwd_kernel<NE>, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, d);       \
+        BPM_CHECK_LAUNCH();                                                                                   \
+        return 0;                                                                                             \
     }
     BPM_LN_BWD(1) BPM_LN_BWD(2) BPM_LN_BWD(5) BPM_LN_BWD(8) BPM_LN_BWD(12) BPM_LN_BWD(16) BPM_LN_BWD(24) BPM_LN_BWD(32)
 #undef BPM_LN_BWD
     return BPM_ERR_ARG;
 }
 
-extern "C" int bpm_rows_cast(int dtype, const float* a, int lda, const float* b, int ldb, void* dst_ct, int ldd,
-                             float* dst_f32, int ldf, float* colsum, int R, int C,
-                             float drop_p, uint64_t seed, uint32_t site, void* stream) {
-    if (!a || R < 1 || C < 1 || lda < C || (b && ldb < C) || (dst_ct && ldd < C) || (dst_f32 && ldf < C)) return BPM_ERR_ARG;
-    if (!dst_ct && !dst_f32 && !colsum) return BPM_ERR_ARG;
-    const DropCfg dr = make_drop(drop_p, seed, site);
-    const int cols = dst_ct ? ldd : C;
-    dim3 grid((R + CAST_ROWS - 1) / CAST_ROWS, (cols + NT - 1) / NT);
-    hipStream_t s = (hipStream_t)stream;
-    BPM_DISPATCH_CT(dtype,
-        hipLaunchKernelGGL(rows_cast_kernel<float>, grid, dim3(NT), 0, s, a, lda, b, ldb, dst_ct, ldd, dst_f32, ldf, colsum, R, C, dr),
-        hipLaunchKernelGGL(rows_cast_kernel<bf16_t>, grid, dim3(NT), 0, s, a, lda, b, ldb, dst_ct, ldd, dst_f32, ldf, colsum, R, C, dr));
+extern "C" int bpm_rows_cast(int dtype, const bpm_cast_problem* q, int n, uint64_t seed, void* stream) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
+    Grp<CastP> g;
+    g.n = n; g.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const bpm_cast_problem& s = q[i];
+        if (!s.a || s.R < 1 || s.C < 1 || s.lda < s.C || (s.b && s.ldb < s.C) || (s.dst_ct && s.ldd < s.C) ||
+            (s.dst_f32 && s.ldf < s.C) || (!s.dst_ct && !s.dst_f32 && !s.colsum))
+            return BPM_ERR_ARG;
+        CastP& p = g.p[i];
+        p.a = s.a; p.lda = s.lda; p.a_is_ct = s.a_is_ct; p.b = s.b; p.ldb = s.ldb;
+        p.dct = s.dst_ct; p.ldd = s.ldd; p.df32 = s.dst_f32; p.ldf = s.ldf; p.colsum = s.colsum;
+        p.R = s.R; p.C = s.C;
+        const int cols = s.dst_ct ? s.ldd : s.C;
+        p.cblk = (cols + NT - 1) / NT;
+        p.drop = make_drop(s.drop_p, seed, s.drop_site);
+        g.blk0[i + 1] = g.blk0[i] + (unsigned)p.cblk * ((s.R + CAST_ROWS - 1) / CAST_ROWS);
+    }
+    BPM_DISPATCH_CT(dtype, rows_cast_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
     BPM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int bpm_gmu2_fwd(const float* a1, const float* a2, const float* ag, const float* x1, const float* x2,
-                            float* out, int R, int d, void* stream) {
-    if (!a1 || !a2 || !ag || !x1 || !x2 || !out || R < 1 || d < 1) return BPM_ERR_ARG;
-    const size_t total = (size_t)R * d;
-    hipLaunchKernelGGL(gmu2_fwd_kernel, dim3(grid_for(total, NT * 4)), dim3(NT), 0, (hipStream_t)stream, a1, a2, ag, x1, x2, out, total);
+static int fill_gmu(Grp<GmuP>& g, const bpm_gmu_problem* q, int n, int d, bool bwd) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP || d < 1) return BPM_ERR_ARG;
+    g.n = n; g.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const bpm_gmu_problem& s = q[i];
+        if (!s.a1 || !s.a2 || !s.ag || !s.x1 || !s.x2 || s.R < 1) return BPM_ERR_ARG;
+        if (bwd ? (!s.dout || !s.da1 || !s.da2 || !s.dag || !s.dx1 || !s.dx2 || s.ldg < d) : !s.out) return BPM_ERR_ARG;
+        GmuP& p = g.p[i];
+        p.a1 = s.a1; p.a2 = s.a2; p.ag = s.ag; p.x1 = s.x1; p.x2 = s.x2; p.out = s.out;
+        p.dout = s.dout; p.da1 = s.da1; p.da2 = s.da2; p.dag = s.dag; p.ldg = s.ldg; p.dx1 = s.dx1; p.dx2 = s.dx2; p.R = s.R;
+        g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)s.R * (bwd ? s.ldg : d), NT * 4, CAP);
+    }
+    return 0;
+}
+
+extern "C" int bpm_gmu2_fwd(const bpm_gmu_problem* q, int n, int d, void* stream) {
+    Grp<GmuP> g;
+    int rc = fill_gmu(g, q, n, d, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gmu2_fwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, d);
     BPM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int bpm_gmu2_bwd(int dtype, const float* dout, const float* a1, const float* a2, const float* ag,
-                            const float* x1, const float* x2, void* da1, void* da2, void* dag, int ldg,
-                            float* dx1, float* dx2, int R, int d, void* stream) {
-    if (!dout || !a1 || !a2 || !ag || !x1 || !x2 || !da1 || !da2 || !dag || !dx1 || !dx2 || R < 1 || d < 1 || ldg < d) return BPM_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const int grid = grid_for((size_t)R * ldg, NT * 4);
-    BPM_DISPATCH_CT(dtype,
-        hipLaunchKernelGGL(gmu2_bwd_kernel<float>, dim3(grid), dim3(NT), 0, s, dout, a1, a2, ag, x1, x2, da1, da2, dag, ldg, dx1, dx2, R, d),
-        hipLaunchKernelGGL(gmu2_bwd_kernel<bf16_t>, dim3(grid), dim3(NT), 0, s, dout, a1, a2, ag, x1, x2, da1, da2, dag, ldg, dx1, dx2, R, d));
+extern "C" int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* q, int n, int d, void* stream) {
+    Grp<GmuP> g;
+    int rc = fill_gmu(g, q, n, d, true);
+    if (rc) return rc;
+    BPM_DISPATCH_CT(dtype, gmu2_bwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, d);
     BPM_CHECK_LAUNCH();
     return 0;
 }

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define BPM_ABI_VERSION 1
-#define BPM_MAX_GROUP 12 /* problems per grouped launch (12 encoders per model) */
+#define BPM_MAX_GROUP 18 /* problems per grouped launch (6 encoders of a level x 3 projections) */
 
 enum { BPM_F32 = 0, BPM_BF16 = 1 };
 enum { BPM_ERR_ARG = -1, BPM_ERR_ALIGN = -2 };
@@ -70,9 +70,9 @@ typedef struct bpm_gemm_problem {
     int ldg;
     float gate_scale;
     float alpha;
-    float drop_p;           /* dropout on element index m*N + n */
-    uint64_t drop_seed;
+    float drop_p;           /* dropout on element index m*N + n, keyed by (call seed, drop_site) */
     uint32_t drop_site;
+    float* colsum;          /* [N] += column sums of v (before + resid), by atomics; or NULL (bias gradients) */
     int flags;              /* BPM_GEMM_* */
     int out_kind;           /* BPM_OUT_* */
     int splitk;             /* >1 needs BPM_GEMM_ATOMIC + BPM_OUT_F32 into a zeroed / accumulating buffer */
@@ -80,7 +80,8 @@ typedef struct bpm_gemm_problem {
     int heads_B, heads_H, heads_T, heads_dh, heads_dhp;
 } bpm_gemm_problem;
 
-int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs /* host */, int nprob, void* stream);
+int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs /* host */, int nprob,
+                     uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused attention (never materialises the [T,S] scores).
@@ -104,75 +105,98 @@ typedef struct bpm_attn_problem {
     int B, H, T, S, dh, dhp;
     int mask_off;
     float dq_scale;
-    float drop_p;           /* on P, element index ((b*H+h)*T + i)*S + j */
-    uint64_t drop_seed;
+    float drop_p;           /* on P, element index ((b*H+h)*T + i)*S + j, keyed by (call seed, drop_site) */
     uint32_t drop_site;
 } bpm_attn_problem;
 
-int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, void* stream);
-int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, void* stream);
+int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
+int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------
- * Input staging.  Replaces x.transpose(1,2) / F.dropout on the text features /
- * .permute(2,0,1) around the Conv1d projections (mmtr.py:741-753): src fp32
- * [B,T,C] -> CT [(t*B+b), ld] (zero pad columns), and its backward.
+ * Row kernels.  All are grouped: `n` problems (<= BPM_MAX_GROUP) per launch,
+ * problem arrays live in HOST memory and are copied into the kernel arguments.
  * ---------------------------------------------------------------------- */
-int bpm_pack_rows_fwd(int dtype, const float* src, void* dst, int B, int T, int C, int ld,
-                      float drop_p, uint64_t seed, uint32_t site, void* stream);
-int bpm_pack_rows_bwd(const float* g, int ldg, float* dsrc, int B, int T, int C,
-                      float drop_p, uint64_t seed, uint32_t site, void* stream);
 
-/* fp32 master weights [rows, cols] -> CT shadows [rows, ld]; table lives in device memory */
+/* Input staging.  Replaces x.transpose(1,2) / F.dropout on the text features /
+ * .permute(2,0,1) around the Conv1d projections (mmtr.py:741-753): src fp32
+ * [B,T,C] -> CT [(t*B+b), ld] (zero pad columns); backward: dsrc[b,t,c] =
+ * drop_mult * g[(t*B+b), c]. */
+typedef struct bpm_pack_problem {
+    const float* src; void* dst;            /* forward */
+    const float* g; int ldg; float* dsrc;   /* backward */
+    int B, T, C, ld;
+    float drop_p; uint32_t drop_site;       /* element index (b*T + t)*C + c */
+} bpm_pack_problem;
+int bpm_pack_rows_fwd(int dtype, const bpm_pack_problem* probs, int n, uint64_t seed, void* stream);
+int bpm_pack_rows_bwd(const bpm_pack_problem* probs, int n, uint64_t seed, void* stream);
+
+/* fp32 master weights -> CT shadows with zero-padded leading dimension; the
+ * descriptor table lives in DEVICE memory (built once, reused every step).
+ * Row r: dst[r*dst_ld + c] = c < cols ? src[r*src_ld + c] : 0 for c < ld. */
 typedef struct bpm_pack_desc {
     const void* src;
     void* dst;
-    int rows, cols, ld;
-    unsigned blk0;          /* first block of this tensor; blocks cover 1024 shadow elements each */
+    int rows, cols, ld, src_ld, dst_ld;
+    unsigned blk0;          /* first block of this tensor; a block covers 1024 (row, c<ld) elements */
 } bpm_pack_desc;
 int bpm_pack_weights(int dtype, const bpm_pack_desc* table_dev, int ndesc, unsigned total_blocks, void* stream);
 
-/* ------------------------------------------------------------------------
- * Encoder prologue.  Replaces embed_scale * x + embed_positions(x[:,:,0]) and
+/* Encoder prologue.  Replaces embed_scale * x + embed_positions(x[:,:,0]) and
  * F.dropout (transformer.py:66-79; position_embedding.py:8-27,62-76):
  * out = dropout(scale*x + table[pos]), pos = t+1 if x[t,b,0] != 0 else 0.
  * `table` is the fp32 sinusoid table [table_rows >= T+1, d] built on the host.
- * ---------------------------------------------------------------------- */
-int bpm_embed_pos_fwd(const float* x, const float* table, int table_rows, float* out, int T, int B, int d,
-                      float scale, float drop_p, uint64_t seed, uint32_t site, void* stream);
-int bpm_embed_pos_bwd(const float* dy, float* dx, int T, int B, int d, float scale, float drop_p,
-                      uint64_t seed, uint32_t site, int accumulate, void* stream);
+ * Backward: x = dy, out = dx, dx (+)= scale * drop_mult * dy. */
+typedef struct bpm_embed_problem {
+    const float* x; float* out;
+    int T, B;
+    int accumulate;                         /* backward only */
+    float drop_p; uint32_t drop_site;       /* element index (t*B + b)*d + c */
+} bpm_embed_problem;
+int bpm_embed_pos_fwd(const bpm_embed_problem* probs, int n, const float* table, int table_rows, int d,
+                      float scale, uint64_t seed, void* stream);
+int bpm_embed_pos_bwd(const bpm_embed_problem* probs, int n, int d, float scale, uint64_t seed, void* stream);
 
-/* ------------------------------------------------------------------------
- * LayerNorm (nn.LayerNorm(d), eps inside sqrt; transformer.py:91,153,167-172,
- * 183-185,227-229).  x fp32 [R,d].  out_dtype: BPM_F32 / BPM_BF16 write CT
- * [R, ldo] with zero pad columns; BPM_OUT_LN_F32 writes plain fp32 [R, ldo].
- * Backward: dx = add + dLN(dy), dgamma/dbeta accumulated by atomics (may be NULL).
- * ---------------------------------------------------------------------- */
-#define BPM_OUT_LN_F32 2
-int bpm_ln_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* out, int ldo,
-               float* mean, float* rstd, int R, int d, float eps, void* stream);
-int bpm_ln_bwd(const float* dy, int ldy, const float* x, const float* mean, const float* rstd, const float* gamma,
-               const float* add, float* dx, float* dgamma, float* dbeta, int R, int d, void* stream);
+/* LayerNorm (nn.LayerNorm(d), eps inside sqrt; transformer.py:91,153,167-172,
+ * 183-185,227-229).  x fp32 [R,d].  Forward writes CT [R, ldo] with zero pad
+ * columns, or plain fp32 [R, ldo] when out_f32; saves mean / rstd [R].
+ * Backward: dx = add + dLN(dy); dgamma/dbeta += by atomics (both or neither). */
+typedef struct bpm_ln_problem {
+    const float* x; const float* gamma; const float* beta;
+    void* out; int ldo; int out_f32;
+    float* mean; float* rstd;
+    int R;
+    const float* dy; int ldy; const float* add; float* dx; float* dgamma; float* dbeta;   /* backward */
+} bpm_ln_problem;
+int bpm_ln_fwd(int dtype, const bpm_ln_problem* probs, int n, int d, float eps, void* stream);
+int bpm_ln_bwd(const bpm_ln_problem* probs, int n, int d, void* stream);
 
-/* y = (a [+ b]) * dropout_mult(r*C + c): CT copy (padded) and/or fp32 copy and/or
- * column sums (+= by atomics).  Used for residual-dropout backward + bias
- * gradients (transformer.py:174-175,189-190) and the level 1->2 residual adds
- * (mmtr.py:799-800). */
-int bpm_rows_cast(int dtype, const float* a, int lda, const float* b, int ldb, void* dst_ct, int ldd,
-                  float* dst_f32, int ldf, float* colsum, int R, int C,
-                  float drop_p, uint64_t seed, uint32_t site, void* stream);
+/* y = (a [+ b]) * dropout_mult(r*C + c); a is fp32 or (a_is_ct) CT.  Outputs,
+ * each optional: CT copy [R, ldd] (pad zeroed), fp32 copy, column sums (+= by
+ * atomics).  Residual-dropout backward + bias gradients (transformer.py:174-175,
+ * 189-190), level 1->2 residual adds (mmtr.py:799-800). */
+typedef struct bpm_cast_problem {
+    const void* a; int lda; int a_is_ct;
+    const float* b; int ldb;
+    void* dst_ct; int ldd;
+    float* dst_f32; int ldf;
+    float* colsum;
+    int R, C;
+    float drop_p; uint32_t drop_site;
+} bpm_cast_problem;
+int bpm_rows_cast(int dtype, const bpm_cast_problem* probs, int n, uint64_t seed, void* stream);
 
-/* ------------------------------------------------------------------------
- * Fusion-GMU gating (GatedMultimodalLayerFeatures.forward, mmtr.py:189-195):
+/* Fusion-GMU gating (GatedMultimodalLayerFeatures.forward, mmtr.py:189-195):
  * out = z*tanh(a1)*x1 + (1-z)*tanh(a2)*x2, z = sigmoid(ag); a1,a2,ag fp32 [R,d]
  * are the three bias-free linears (GEMM outputs).  Backward writes da1,da2,dag
- * as CT [R, ldg] and the direct terms dx1 = dout*z*tanh(a1), dx2 likewise.
- * ---------------------------------------------------------------------- */
-int bpm_gmu2_fwd(const float* a1, const float* a2, const float* ag, const float* x1, const float* x2,
-                 float* out, int R, int d, void* stream);
-int bpm_gmu2_bwd(int dtype, const float* dout, const float* a1, const float* a2, const float* ag,
-                 const float* x1, const float* x2, void* da1, void* da2, void* dag, int ldg,
-                 float* dx1, float* dx2, int R, int d, void* stream);
+ * as CT [R, ldg] and the direct terms dx1 = dout*z*tanh(a1), dx2 likewise. */
+typedef struct bpm_gmu_problem {
+    const float* a1; const float* a2; const float* ag; const float* x1; const float* x2;
+    float* out;
+    const float* dout; void* da1; void* da2; void* dag; int ldg; float* dx1; float* dx2;   /* backward */
+    int R;
+} bpm_gmu_problem;
+int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
+int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
 #ifdef __cplusplus
 }

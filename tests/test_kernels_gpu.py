@@ -119,16 +119,18 @@ def test_gemm_epilogues_grouped(dtype):
     o1 = torch.full((M, pad32(N)), float("nan"), device=DEV).to(ctt)
     o2 = torch.full((M, N), float("nan"), device=DEV)
     o3 = torch.zeros(B_, H, T_, dhp, device=DEV, dtype=ctt)
+    cs1 = torch.ones(N, device=DEV)
     p1 = ops.gemm_problem(A, W, o1, M, N, K, A.shape[1], W.shape[1], pad32(N), bias_n=bias, flags=F_RELU,
-                          drop_p=0.3, drop_seed=77, drop_site=5, out_kind=OUT_CT)
+                          drop_p=0.3, drop_site=5, out_kind=OUT_CT, colsum=cs1)
     p2 = ops.gemm_problem(A, W, o2, M, N, K, A.shape[1], W.shape[1], N, gate=gate, ldg=gate.shape[1], gate_scale=1.25)
     p3 = ops.gemm_problem(A, W, o3, M, N, K, A.shape[1], W.shape[1], 0, bias_n=bias, alpha=0.2, out_kind=OUT_HEADS,
                           heads=(B_, H, T_, dh, dhp))
-    ops.gemm_grouped(dtype, GEMM_NT, [p1, p2, p3])
+    ops.gemm_grouped(dtype, GEMM_NT, [p1, p2, p3], seed=77)
     acc = Ar.double() @ Wr.double().T
     t = tol(dtype) if dtype == BPM_F32 else 1e-2
     ref1 = torch.relu(acc + bias.cpu().double()) * drop_mult((M, N), 0.3, 77, 5).double()
     close(o1[:, :N].float(), ref1, t, "relu+dropout CT")
+    close(cs1, 1.0 + ref1.sum(0), t, "gemm colsum")
     assert (o1[:, N:].float() == 0).all(), "pad columns must be zero"
     frac = (ref1 == 0).double().mean().item()
     assert 0.3 < frac < 0.9
@@ -181,8 +183,8 @@ def test_attention_fwd_bwd(dtype, B, H, T, S, dh, masked, pdrop):
     delta = torch.zeros(B, H, T, device=DEV)
     dQ, dK, dV = (torch.zeros(L * B, ld, device=DEV, dtype=ctt) for L in (T, S, S))
     p = ops.attn_problem(Q, K, V, O, ld, lse, B, H, T, S, dh, dhp, off, dO=dO, delta=delta, dQ=dQ, lddq=ld, dK=dK, lddk=ld,
-                         dV=dV, lddv=ld, dq_scale=1.0, drop_p=pdrop, drop_seed=9, drop_site=3)
-    ops.attn_fwd(dtype, [p])
+                         dV=dV, lddv=ld, dq_scale=1.0, drop_p=pdrop, drop_site=3)
+    ops.attn_fwd(dtype, [p], seed=9)
     t = 3e-5 if dtype == BPM_F32 else 2e-2
 
     def rows(x, L):      # row-major [(l*B+b), h*dh+c] -> [B,H,L,dh]
@@ -191,7 +193,7 @@ def test_attention_fwd_bwd(dtype, B, H, T, S, dh, masked, pdrop):
     close(rows(O, T), o_ref.detach(), t, "O")
     close(lse, lse_ref.detach(), t, "lse")
     assert (O[:, d:].float() == 0).all()
-    ops.attn_bwd(dtype, [p])
+    ops.attn_bwd(dtype, [p], seed=9)
     tb = 1e-4 if dtype == BPM_F32 else 4e-2
     close(rows(dQ, T), q.grad, tb, "dQ")
     close(rows(dK, S), k.grad, tb, "dK")
@@ -204,14 +206,19 @@ def test_pack_rows_and_embed_pos(dtype):
     B, T, Cn = 3, 7, 35
     ld = pad32(Cn)
     src = rnd(B, T, Cn, seed=31)
+    src2 = rnd(B, 4, 74, seed=30)
     dst = torch.full((T * B, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
-    ops.pack_rows_fwd(dtype, src.to(DEV), dst, B, T, Cn, ld, 0.25, 5, 2)
+    dst2 = torch.full((4 * B, 96), float("nan"), device=DEV).to(ops.ct_torch(dtype))
+    srcd, src2d = src.to(DEV), src2.to(DEV)      # problem structs hold raw pointers: keep the tensors alive
+    ops.pack_rows_fwd(dtype, [ops.pack_problem(B, T, Cn, ld, src=srcd, dst=dst, drop_p=0.25, drop_site=2),
+                              ops.pack_problem(B, 4, 74, 96, src=src2d, dst=dst2)], seed=5)
     ref = (src * drop_mult((B, T, Cn), 0.25, 5, 2)).permute(1, 0, 2).reshape(T * B, Cn)
     close(dst[:, :Cn].float(), ref.to(ops.ct_torch(dtype)).float(), 1e-6, "pack fwd")
     assert (dst[:, Cn:].float() == 0).all()
+    close(dst2[:, :74].float(), src2.permute(1, 0, 2).reshape(4 * B, 74).to(ops.ct_torch(dtype)).float(), 1e-6, "pack fwd 2")
     g = rnd(T * B, ld, seed=32).to(DEV)
     dsrc = torch.full((B, T, Cn), float("nan"), device=DEV)
-    ops.pack_rows_bwd(g, ld, dsrc, B, T, Cn, 0.25, 5, 2)
+    ops.pack_rows_bwd([ops.pack_problem(B, T, Cn, 0, g=g, ldg=ld, dsrc=dsrc, drop_p=0.25, drop_site=2)], seed=5)
     refb = g.cpu()[:, :Cn].reshape(T, B, Cn).permute(1, 0, 2) * drop_mult((B, T, Cn), 0.25, 5, 2)
     close(dsrc, refb, 1e-6, "pack bwd")
 
@@ -220,14 +227,20 @@ def test_pack_rows_and_embed_pos(dtype):
     x = rnd(T2, B2, d, seed=33)
     x[2, 1, 0] = 0.0
     x[-2:] = 0.0
+    x3 = rnd(5, B2, d, seed=35)
     table = O.sinusoid_table(T2 + 1, d).to(DEV)
     out = torch.empty(T2, B2, d, device=DEV)
-    ops.embed_pos_fwd(x.to(DEV), table, out, T2, B2, d, math.sqrt(d), 0.25, 1, 4)
+    out3 = torch.empty(5, B2, d, device=DEV)
+    xd, x3d = x.to(DEV), x3.to(DEV)
+    ops.embed_pos_fwd([ops.embed_problem(xd, out, T2, B2, drop_p=0.25, drop_site=4),
+                       ops.embed_problem(x3d, out3, 5, B2)], table, d, math.sqrt(d), seed=1)
     ref = (math.sqrt(d) * x + O.pos_embedding(x)) * drop_mult((T2, B2, d), 0.25, 1, 4)
     close(out, ref, 1e-6, "embed_pos fwd")
+    close(out3, math.sqrt(d) * x3 + O.pos_embedding(x3), 1e-6, "embed_pos fwd 2")
     dy = rnd(T2, B2, d, seed=34)
     dx = torch.ones(T2, B2, d, device=DEV)
-    ops.embed_pos_bwd(dy.to(DEV), dx, T2, B2, d, math.sqrt(d), 0.25, 1, 4, accumulate=True)
+    dyd = dy.to(DEV)
+    ops.embed_pos_bwd([ops.embed_problem(dyd, dx, T2, B2, accumulate=True, drop_p=0.25, drop_site=4)], d, math.sqrt(d), seed=1)
     close(dx, 1.0 + math.sqrt(d) * dy * drop_mult((T2, B2, d), 0.25, 1, 4), 1e-6, "embed_pos bwd")
 
 
@@ -243,19 +256,22 @@ def test_layernorm(dtype, R, d):
     (y * dy).sum().backward()
     ld = pad32(d)
     out = torch.full((R, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
-    mean, rstd = torch.empty(R, device=DEV), torch.empty(R, device=DEV)
+    outf = torch.empty(R, d, device=DEV)
+    mean, rstd, mean2, rstd2 = (torch.empty(R, device=DEV) for _ in range(4))
     xd, gd, bd = x.detach().to(DEV), gamma.detach().to(DEV), beta.detach().to(DEV)
-    ops.ln_fwd(dtype, xd, gd, bd, out, ld, mean, rstd, R, d)
+    ops.ln_fwd(dtype, [ops.ln_problem(xd, gd, bd, mean, rstd, R, out=out, ldo=ld),
+                       ops.ln_problem(xd, gd, bd, mean2, rstd2, R, out=outf, ldo=d, out_f32=True)], d)
     close(out[:, :d].float(), y.detach(), 2e-5 if dtype == BPM_F32 else 1e-2, "ln fwd")
     assert (out[:, d:].float() == 0).all()
-    outf = torch.empty(R, d, device=DEV)
-    ops.ln_fwd(ops.LN_OUT_F32, xd, gd, bd, outf, d, mean, rstd, R, d)
     close(outf, y.detach(), 2e-5, "ln fwd f32")
     add = rnd(R, d, seed=45).to(DEV)
-    dx = torch.empty(R, d, device=DEV)
+    dx, dx2 = torch.empty(R, d, device=DEV), torch.empty(R, d, device=DEV)
     dgam, dbet = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
-    ops.ln_bwd(dy.to(DEV), d, xd, mean, rstd, gd, add, dx, dgam, dbet, R, d)
+    dyd = dy.to(DEV)
+    ops.ln_bwd([ops.ln_problem(xd, gd, None, mean, rstd, R, dy=dyd, ldy=d, add=add, dx=dx, dgamma=dgam, dbeta=dbet),
+                ops.ln_problem(xd, gd, None, mean, rstd, R, dy=dyd, ldy=d, dx=dx2)], d)
     close(dx, x.grad + add.cpu(), 1e-4, "ln dx")
+    close(dx2, x.grad, 1e-4, "ln dx (no add, no param grads)")
     close(dgam, gamma.grad, 1e-4, "ln dgamma")
     close(dbet, beta.grad, 1e-4, "ln dbeta")
 
@@ -264,17 +280,23 @@ def test_layernorm(dtype, R, d):
 def test_rows_cast_and_gmu(dtype):
     R, Cn = 77, 300
     ld = pad32(Cn)
+    ctt = ops.ct_torch(dtype)
     a, b = rnd(R, Cn, seed=51), rnd(R, Cn, seed=52)
-    dct = torch.full((R, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
+    dct = torch.full((R, ld), float("nan"), device=DEV).to(ctt)
     df = torch.empty(R, Cn, device=DEV)
     cs = torch.ones(Cn, device=DEV)
-    ops.rows_cast(dtype, a.to(DEV), Cn, R, Cn, b=b.to(DEV), ldb=Cn, dst_ct=dct, ldd=ld, dst_f32=df, ldf=Cn, colsum=cs,
-                  drop_p=0.1, seed=3, site=9)
+    act, actr = to_ct(rnd(40, 70, seed=53), dtype)
+    cs2 = torch.zeros(70, device=DEV)
+    ad, bd_ = a.to(DEV), b.to(DEV)
+    ops.rows_cast(dtype, [ops.cast_problem(ad, Cn, R, Cn, b=bd_, ldb=Cn, dst_ct=dct, ldd=ld, dst_f32=df, ldf=Cn,
+                                           colsum=cs, drop_p=0.1, drop_site=9),
+                          ops.cast_problem(act, act.shape[1], 40, 70, a_is_ct=True, colsum=cs2)], seed=3)
     ref = (a + b) * drop_mult((R, Cn), 0.1, 3, 9)
     close(df, ref, 1e-6, "cast f32")
-    close(dct[:, :Cn].float(), ref.to(ops.ct_torch(dtype)).float(), 1e-6, "cast ct")
+    close(dct[:, :Cn].float(), ref.to(ctt).float(), 1e-6, "cast ct")
     assert (dct[:, Cn:].float() == 0).all()
     close(cs, 1.0 + ref.sum(0), 1e-4, "colsum")
+    close(cs2, actr.sum(0), 1e-4, "colsum of a CT input")
 
     d = 24
     ts = [rnd(R, d, seed=60 + i).requires_grad_(True) for i in range(5)]
@@ -285,12 +307,13 @@ def test_rows_cast_and_gmu(dtype):
     (y * dout).sum().backward()
     dv = [t.detach().to(DEV) for t in ts]
     out = torch.empty(R, d, device=DEV)
-    ops.gmu2_fwd(*dv, out, R, d)
+    ops.gmu2_fwd([ops.gmu_problem(*dv, R, out=out)], d)
     close(out, y.detach(), 1e-5, "gmu fwd")
     ldg = pad32(d)
-    das = [torch.full((R, ldg), float("nan"), device=DEV).to(ops.ct_torch(dtype)) for _ in range(3)]
+    das = [torch.full((R, ldg), float("nan"), device=DEV).to(ctt) for _ in range(3)]
     dx1, dx2 = torch.empty(R, d, device=DEV), torch.empty(R, d, device=DEV)
-    ops.gmu2_bwd(dtype, dout.to(DEV), *dv, *das, ldg, dx1, dx2, R, d)
+    doutd = dout.to(DEV)
+    ops.gmu2_bwd(dtype, [ops.gmu_problem(*dv, R, dout=doutd, da1=das[0], da2=das[1], dag=das[2], ldg=ldg, dx1=dx1, dx2=dx2)], d)
     t = 1e-5 if dtype == BPM_F32 else 1e-2
     for got, ref_, n in zip(das, (a1, a2, ag), ("da1", "da2", "dag")):
         close(got[:, :d].float(), ref_.grad, t, n)
