@@ -89,7 +89,7 @@ class LnProblem(C.Structure):
 class CastProblem(C.Structure):
     _fields_ = [("a", C.c_void_p), ("lda", C.c_int), ("a_is_ct", C.c_int),
                 ("b", C.c_void_p), ("ldb", C.c_int),
-                ("dst_ct", C.c_void_p), ("ldd", C.c_int),
+                ("dst_ct", C.c_void_p), ("ldd", C.c_int), ("ct_cols", C.c_int),
                 ("dst_f32", C.c_void_p), ("ldf", C.c_int),
                 ("colsum", C.c_void_p), ("R", C.c_int), ("C", C.c_int),
                 ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
@@ -148,7 +148,16 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_DEBUG_SYNC = bool(int(os.environ.get("BPMULT_DEBUG_SYNC", "0")))
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().bpm_error_string(rc)
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+    if _DEBUG_SYNC:        # debugging aid: localise an asynchronous kernel fault to its launch
+        import sys
+        import torch
+        print(f"[bpmult] {what} ...", end="", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        print(" ok", file=sys.stderr, flush=True)

@@ -275,7 +275,7 @@ constexpr int CAST_ROWS = 32;
 
 struct CastP {
     const void* a; int lda; int a_is_ct; const float* b; int ldb;
-    void* dct; int ldd; float* df32; int ldf; float* colsum;
+    void* dct; int ldd; int ctw; float* df32; int ldf; float* colsum;
     int R, C; int cblk;   // column blocks
     DropCfg drop;
 };
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NT) void rows_cast_kernel(const Grp<CastP> grp) {
     const int c = (bid % P.cblk) * NT + threadIdx.x;
     const int r0 = (bid / P.cblk) * CAST_ROWS;
     const int r1 = min(P.R, r0 + CAST_ROWS);
-    const int cmax = P.dct ? P.ldd : P.C;
+    const int cmax = P.dct ? P.ctw : P.C;
     if (c >= cmax) return;
     float s = 0.f;
     for (int r = r0; r < r1; ++r) {
@@ -509,9 +509,10 @@ extern "C" int bpm_rows_cast(int dtype, const bpm_cast_problem* q, int n, uint64
             return BPM_ERR_ARG;
         CastP& p = g.p[i];
         p.a = s.a; p.lda = s.lda; p.a_is_ct = s.a_is_ct; p.b = s.b; p.ldb = s.ldb;
-        p.dct = s.dst_ct; p.ldd = s.ldd; p.df32 = s.dst_f32; p.ldf = s.ldf; p.colsum = s.colsum;
+        p.dct = s.dst_ct; p.ldd = s.ldd; p.ctw = s.ct_cols > 0 ? s.ct_cols : s.ldd; p.df32 = s.dst_f32; p.ldf = s.ldf; p.colsum = s.colsum;
         p.R = s.R; p.C = s.C;
-        const int cols = s.dst_ct ? s.ldd : s.C;
+        if (s.dst_ct && (p.ctw < s.C || p.ctw > s.ldd)) return BPM_ERR_ARG;
+        const int cols = s.dst_ct ? p.ctw : s.C;
         p.cblk = (cols + NT - 1) / NT;
         p.drop = make_drop(s.drop_p, seed, s.drop_site);
         g.blk0[i + 1] = g.blk0[i] + (unsigned)p.cblk * ((s.R + CAST_ROWS - 1) / CAST_ROWS);

@@ -1,0 +1,552 @@
+"""Host-side orchestration of the BPMulT hot path on one MI355X.
+
+Nothing here computes: it owns device buffers (allocated through torch), builds
+the per-layer problem tables once per batch shape, and replays them through the
+C ABI (ops.py) in forward and in a hand-ordered backward.  The design follows
+the hardware, not the reference's call order:
+
+* ParamStore -- every trunk parameter is a view into ONE flat fp32 master
+  buffer, its gradient a view into ONE flat fp32 gradient buffer (what the
+  RCCL all-reduce buckets and a fused optimizer want), and every 2-D weight has
+  a CT (f32 / bf16) "shadow" with a 32-padded leading dimension, refreshed by a
+  single table-driven launch per step.
+* EncoderGroupPlan -- the independent encoders of one level (six in BPMulT,
+  SURVEY.md 3.2) advance layer by layer in lock-step; every kernel launch of a
+  layer serves all of them (grouped GEMM / attention / row kernels), so small
+  per-encoder problems still fill 256 CUs and launches drop 6x.
+* Activations needed by backward are kept in per-layer buffers in the layout
+  the backward GEMMs consume (CT row-major for wgrad operands, head-major for
+  attention); the [T,S] attention matrix is never stored (only row LSE).
+
+Reference semantics implemented (file:line): transformer.py:52-93 (encoder),
+141-195 (layer variants), multihead_attention.py:52-135, mmtr.py:189-195 (GMU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,
+                   AttnProblem, CastProblem, EmbedProblem, GemmProblem, GmuProblem, LnProblem, PackDesc, PackProblem)
+from .ops import pad32
+
+# dropout site ids (unique per encoder / layer / op; the seed changes per step)
+S_EMB_Q, S_EMB_K, S_EMB_V, S_ATTN, S_RES1, S_RELU, S_RES2, S_ATTN_SELF, S_RES0 = range(9)
+SITE_TEXT = 1 << 20
+
+
+def site(enc_id: int, layer: int, op: int) -> int:
+    return (enc_id << 12) | (layer << 4) | op
+
+
+def dhp_for(dh: int) -> int:
+    if dh <= 32:
+        return 32
+    if dh <= 64:
+        return 64
+    if dh <= 128:
+        return 128
+    raise ValueError(f"head_dim {dh} > 128 is not supported by the attention kernels")
+
+
+_TABLES: Dict[Tuple[int, int, str], torch.Tensor] = {}
+
+
+def sinusoid_table(n_pos: int, d: int, device) -> torch.Tensor:
+    """fp32 [n_pos, d] table of position_embedding.py:44-60, built once on the
+    host with the same torch CPU ops as the reference (bit-identical rows) and
+    kept resident on the device."""
+    key = (d, str(device))
+    t = _TABLES.get(key)
+    if t is None or t.shape[0] < n_pos:
+        n = max(n_pos, 513)
+        half = d // 2
+        step = math.log(10000.0) / (half - 1)
+        freq = torch.exp(torch.arange(half, dtype=torch.float32) * -step)
+        ang = torch.arange(n, dtype=torch.float32)[:, None] * freq[None, :]
+        tab = torch.cat([ang.sin(), ang.cos()], dim=1)
+        if d % 2 == 1:
+            tab = torch.cat([tab, torch.zeros(n, 1)], dim=1)
+        tab[0].zero_()
+        t = tab.contiguous().to(device)
+        _TABLES[key] = t
+    return t
+
+
+# ----------------------------------------------------------------------------
+# parameters
+# ----------------------------------------------------------------------------
+class ParamStore:
+    """Flat fp32 master + gradient buffers and CT weight shadows for a set of
+    nn.Parameters (all on one CUDA device)."""
+
+    ALIGN = 64  # elements
+
+    def __init__(self, named_params: Sequence[Tuple[str, torch.nn.Parameter]], dtype: int):
+        self.dtype = dtype
+        self.names = [n for n, _ in named_params]
+        self.params = {n: p for n, p in named_params}
+        dev = named_params[0][1].device
+        if dev.type != "cuda":
+            raise RuntimeError("BPMulT hot path: parameters must live on a CUDA (HIP) device; there is no CPU path")
+        self.device = dev
+        self.off: Dict[str, int] = {}
+        total = 0
+        for n, p in named_params:
+            self.off[n] = total
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = total
+        self.master = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for n, p in named_params:
+                v = self.master[self.off[n]: self.off[n] + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+        self._gviews = {n: self.gflat[self.off[n]: self.off[n] + p.numel()].view(p.shape) for n, p in named_params}
+        self._shadow_specs: List[Tuple[str, int, int, int, int, int, int, int]] = []
+        self._shadow_off: Dict[str, int] = {}
+        self._shadow_total = 0
+        self.shadow_flat: Optional[torch.Tensor] = None
+        self._table = None
+        self._master_ptr = self.master.data_ptr()
+
+    # -- masters / grads ------------------------------------------------------
+    def p(self, name: str) -> torch.Tensor:
+        return self.params[name].data
+
+    def g(self, name: str) -> torch.Tensor:
+        return self._gviews[name]
+
+    def gptr(self, name: str, elem_off: int = 0) -> int:
+        return self._gviews[name].data_ptr() + 4 * elem_off
+
+    def still_flat(self) -> bool:
+        """False after model.to()/.cuda()/.float() replaced the parameter storages."""
+        n0, n1 = self.names[0], self.names[-1]
+        return (self.params[n0].data_ptr() == self._master_ptr + 4 * self.off[n0]
+                and self.params[n1].data_ptr() == self._master_ptr + 4 * self.off[n1])
+
+    def begin_backward(self) -> None:
+        """Gradients accumulate into gflat like autograd accumulates into .grad:
+        a parameter whose .grad is None starts from zero."""
+        fresh = self.params[self.names[0]].grad is None
+        if fresh:
+            self.gflat.zero_()
+
+    def end_backward(self) -> None:
+        for n in self.names:
+            p = self.params[n]
+            if p.grad is None and p.requires_grad:
+                p.grad = self._gviews[n]
+
+    # -- shadows --------------------------------------------------------------
+    def add_shadow(self, key: str, name: str, rows: int, cols: int, *, src_col0: int = 0, src_ld: Optional[int] = None,
+                   dst_ld: Optional[int] = None, dst_col0: int = 0, base_key: Optional[str] = None) -> None:
+        """Register a CT shadow [rows, dst_ld] of master `name` viewed as [rows, src_ld][:, src_col0:src_col0+cols].
+        base_key: write into an already registered shadow (column block dst_col0) instead of a new one."""
+        ld = pad32(cols)
+        src_ld = cols if src_ld is None else src_ld
+        dst_ld = ld if dst_ld is None else dst_ld
+        if base_key is None:
+            self._shadow_off[key] = self._shadow_total
+            off = self._shadow_total
+            self._shadow_total += rows * dst_ld
+        else:
+            off = self._shadow_off[base_key]
+            self._shadow_off[key] = off + dst_col0
+        self._shadow_specs.append((name, rows, cols, ld, src_ld, dst_ld, src_col0, off + dst_col0))
+
+    def finalize_shadows(self) -> None:
+        ct = ops.ct_torch(self.dtype)
+        self.shadow_flat = torch.zeros(max(self._shadow_total, 32), device=self.device, dtype=ct)
+        esz = self.shadow_flat.element_size()
+        descs, blk = [], 0
+        for (name, rows, cols, ld, src_ld, dst_ld, src_col0, off) in self._shadow_specs:
+            d = PackDesc()
+            d.src = self.params[name].data_ptr() + 4 * src_col0
+            d.dst = self.shadow_flat.data_ptr() + esz * off
+            d.rows, d.cols, d.ld, d.src_ld, d.dst_ld, d.blk0 = rows, cols, ld, src_ld, dst_ld, blk
+            blk += (rows * ld + 1023) // 1024
+            descs.append(d)
+        self._ndesc, self._nblk = len(descs), blk
+        if descs:
+            arr = (PackDesc * len(descs))(*descs)
+            raw = bytes(memoryview(arr))
+            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+
+    def sptr(self, key: str, elem_off: int = 0) -> int:
+        return self.shadow_flat.data_ptr() + self.shadow_flat.element_size() * (self._shadow_off[key] + elem_off)
+
+    def refresh_shadows(self) -> None:
+        if self._table is not None:
+            ops.pack_weights(self.dtype, self._table, self._ndesc, self._nblk)
+
+
+# ----------------------------------------------------------------------------
+# encoder group
+# ----------------------------------------------------------------------------
+@dataclass
+class EncoderDesc:
+    """One encoder of a lock-step group.  `prefix` selects its parameters in the
+    ParamStore (reference state_dict names, e.g. 'trans_l_with_a.')."""
+    prefix: str
+    enc_id: int
+    T: int
+    S: int
+    attn_dropout: float
+
+
+@dataclass
+class GroupCfg:
+    d: int
+    H: int
+    layers: int
+    relu_dropout: float
+    res_dropout: float
+    embed_dropout: float
+    attn_mask: bool
+    biprojection: bool
+
+
+def _splitk(tiles_total: int, k: int) -> int:
+    return max(1, min(k // 512, 1024 // max(1, tiles_total), 16))
+
+
+class EncoderGroupPlan:
+    """Buffers + launch tables for G encoders x L layers at batch size B."""
+
+    def __init__(self, store: ParamStore, cfg: GroupCfg, encs: Sequence[EncoderDesc], B: int):
+        self.store, self.cfg, self.encs, self.B = store, cfg, list(encs), B
+        self.dtype = store.dtype
+        d, H = cfg.d, cfg.H
+        if d % H:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.dh = d // H
+        self.dhp = dhp_for(self.dh)
+        self.ld, self.ld4 = pad32(d), pad32(4 * d)
+        self.scale = self.dh ** -0.5
+        dev, ct = store.device, ops.ct_torch(self.dtype)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        L = cfg.layers
+        self.buf: List[dict] = []
+        for e in self.encs:
+            R, Rk = e.T * B, e.S * B
+            b = dict(R=R, Rk=Rk)
+            b["x"] = [z(R, d) for _ in range(L + 1)]
+            b["ke"], b["ve"] = z(Rk, d), z(Rk, d)
+            b["out"] = z(e.T, B, d)
+            b["stf"] = (z(R), z(R))
+            for nm, shape, dt in (("xn", (R, self.ld), ct), ("kn", (Rk, self.ld), ct), ("vn", (Rk, self.ld), ct),
+                                  ("qh", (B, H, e.T, self.dhp), ct), ("kh", (B, H, e.S, self.dhp), ct),
+                                  ("vh", (B, H, e.S, self.dhp), ct), ("ao", (R, self.ld), ct), ("lse", (B, H, e.T), torch.float32),
+                                  ("xmid", (R, d), torch.float32), ("xn2", (R, self.ld), ct), ("h1", (R, self.ld4), ct),
+                                  ("st0m", (R,), torch.float32), ("st0r", (R,), torch.float32),
+                                  ("st1m", (R,), torch.float32), ("st1r", (R,), torch.float32),
+                                  ("stkm", (Rk,), torch.float32), ("stkr", (Rk,), torch.float32),
+                                  ("stvm", (Rk,), torch.float32), ("stvr", (Rk,), torch.float32)):
+                b[nm] = [z(*shape, dt=dt) for _ in range(L)]
+            if cfg.biprojection:
+                for nm, shape, dt in (("qs", (B, H, e.T, self.dhp), ct), ("ks", (B, H, e.T, self.dhp), ct),
+                                      ("vs", (B, H, e.T, self.dhp), ct), ("aos", (R, self.ld), ct),
+                                      ("lses", (B, H, e.T), torch.float32), ("xmid0", (R, d), torch.float32),
+                                      ("xq", (R, self.ld), ct), ("st2m", (R,), torch.float32), ("st2r", (R,), torch.float32)):
+                    b[nm] = [z(*shape, dt=dt) for _ in range(L)]
+                b["dks"], b["dvs"] = z(R, self.ld, dt=ct), z(R, self.ld, dt=ct)
+            # backward temporaries (shared by all layers)
+            b["dx"], b["dxn"] = z(R, d), z(R, d)
+            b["dy"], b["dh1"] = z(R, self.ld, dt=ct), z(R, self.ld4, dt=ct)
+            b["dao"] = z(B, H, e.T, self.dhp, dt=ct)
+            b["delta"] = z(B, H, e.T)
+            b["dq"], b["dk"], b["dv"] = z(R, self.ld, dt=ct), z(Rk, self.ld, dt=ct), z(Rk, self.ld, dt=ct)
+            b["dkn"], b["dvn"], b["dke"], b["dve"] = z(Rk, d), z(Rk, d), z(Rk, d), z(Rk, d)
+            b["dxq"], b["dxk"], b["dxv"] = z(e.T, B, d), z(e.S, B, d), z(e.S, B, d)
+            self.buf.append(b)
+        self.table = sinusoid_table(max(max(e.T, e.S) for e in self.encs) + 1, d, dev)
+        self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
+        self._bwd = {True: self._build_bwd(True), False: self._build_bwd(False)}
+
+    # -- helpers ----------------------------------------------------------------
+    def _mask_off(self, T: int, S: int) -> int:
+        return 1 + abs(S - T) if self.cfg.attn_mask else 0
+
+    def _pn(self, e: EncoderDesc, i: int, leaf: str) -> str:
+        return f"{e.prefix}layers.{i}.{leaf}"
+
+    def _gemm(self, variant, probs):
+        return (ops.gemm_grouped, self.dtype, variant, ops.array(GemmProblem, probs))
+
+    # -- forward tables ---------------------------------------------------------
+    def _build_fwd(self, training: bool):
+        c, st, B, d, H = self.cfg, self.store, self.B, self.cfg.d, self.cfg.H
+        ld, ld4, dh, dhp = self.ld, self.ld4, self.dh, self.dhp
+        pr = (lambda p: p) if training else (lambda p: 0.0)
+        steps = []
+        A = ops.array
+        for i in range(c.layers):
+            ln, qkv, att, outp, ln2, fc1, fc2 = [], [], [], [], [], [], []
+            pre = dict(ln=[], qkv=[], att=[], outp=[], cast=[])      # biprojection self-attention half
+            for e, b in zip(self.encs, self.buf):
+                R, Rk = b["R"], b["Rk"]
+                P = lambda leaf: st.p(self._pn(e, i, leaf))
+                ipw = self._pn(e, i, "self_attn.in_proj_weight")
+                ipb = P("self_attn.in_proj_bias")
+                wo, w1, w2 = (self._pn(e, i, n) for n in ("self_attn.out_proj.weight", "fc1.weight", "fc2.weight"))
+                g0, b0 = P("layer_norms.0.weight"), P("layer_norms.0.bias")
+                g1, b1 = P("layer_norms.1.weight"), P("layer_norms.1.bias")
+
+                def proj(Ain, rows, which, Cout, Tlen):
+                    return ops.gemm_problem(Ain, st.sptr(ipw, which * d * ld), Cout, rows, d, d, ld, ld, 0,
+                                            bias_n=ipb[which * d:(which + 1) * d], alpha=self.scale if which == 0 else 1.0,
+                                            out_kind=OUT_HEADS, heads=(B, H, Tlen, dh, dhp))
+
+                x_in = b["x"][i]
+                if c.biprojection:
+                    g2, b2 = P("layer_norms.2.weight"), P("layer_norms.2.bias")
+                    pre["ln"].append(ops.ln_problem(x_in, g0, b0, b["st0m"][i], b["st0r"][i], R, out=b["xn"][i], ldo=ld))
+                    for w, dst in ((0, b["qs"][i]), (1, b["ks"][i]), (2, b["vs"][i])):
+                        pre["qkv"].append(proj(b["xn"][i], R, w, dst, e.T))
+                    pre["att"].append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H,
+                                                       e.T, e.T, dh, dhp, self._mask_off(e.T, e.T),
+                                                       drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
+                    pre["outp"].append(ops.gemm_problem(b["aos"][i], st.sptr(wo), b["xmid0"][i], R, d, d, ld, ld, d,
+                                                        bias_n=P("self_attn.out_proj.bias"), resid=x_in, ldr=d,
+                                                        drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
+                    pre["cast"].append(ops.cast_problem(b["xmid0"][i], d, R, d, dst_ct=b["xq"][i], ldd=ld))
+                    q_src, resid_src = b["xq"][i], b["xmid0"][i]
+                    gk, bk, gf, bf = g1, b1, g2, b2
+                    stf = (b["st2m"][i], b["st2r"][i])
+                else:
+                    ln.append(ops.ln_problem(x_in, g0, b0, b["st0m"][i], b["st0r"][i], R, out=b["xn"][i], ldo=ld))
+                    q_src, resid_src = b["xn"][i], x_in
+                    gk, bk, gf, bf = g0, b0, g1, b1
+                    stf = (b["st1m"][i], b["st1r"][i])
+                ln.append(ops.ln_problem(b["ke"], gk, bk, b["stkm"][i], b["stkr"][i], Rk, out=b["kn"][i], ldo=ld))
+                ln.append(ops.ln_problem(b["ve"], gk, bk, b["stvm"][i], b["stvr"][i], Rk, out=b["vn"][i], ldo=ld))
+                qkv.append(proj(q_src, R, 0, b["qh"][i], e.T))
+                qkv.append(proj(b["kn"][i], Rk, 1, b["kh"][i], e.S))
+                qkv.append(proj(b["vn"][i], Rk, 2, b["vh"][i], e.S))
+                att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
+                                            self._mask_off(e.T, e.S), drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
+                outp.append(ops.gemm_problem(b["ao"][i], st.sptr(wo), b["xmid"][i], R, d, d, ld, ld, d,
+                                             bias_n=P("self_attn.out_proj.bias"), resid=resid_src, ldr=d,
+                                             drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES1)))
+                ln2.append(ops.ln_problem(b["xmid"][i], gf, bf, stf[0], stf[1], R, out=b["xn2"][i], ldo=ld))
+                fc1.append(ops.gemm_problem(b["xn2"][i], st.sptr(w1), b["h1"][i], R, 4 * d, d, ld, ld, ld4, bias_n=P("fc1.bias"),
+                                            flags=F_RELU, drop_p=pr(c.relu_dropout), drop_site=site(e.enc_id, i, S_RELU),
+                                            out_kind=OUT_CT))
+                fc2.append(ops.gemm_problem(b["h1"][i], st.sptr(w2), b["x"][i + 1], R, d, 4 * d, ld4, ld4, d, bias_n=P("fc2.bias"),
+                                            resid=b["xmid"][i], ldr=d, drop_p=pr(c.res_dropout),
+                                            drop_site=site(e.enc_id, i, S_RES2)))
+            if c.biprojection:
+                steps += [(ops.ln_fwd, self.dtype, A(LnProblem, pre["ln"]), d),
+                          self._gemm(GEMM_NT, pre["qkv"]),
+                          (ops.attn_fwd, self.dtype, A(AttnProblem, pre["att"])),
+                          self._gemm(GEMM_NT, pre["outp"]),
+                          (ops.rows_cast, self.dtype, A(CastProblem, pre["cast"]))]
+            steps += [(ops.ln_fwd, self.dtype, A(LnProblem, ln), d),
+                      self._gemm(GEMM_NT, qkv),
+                      (ops.attn_fwd, self.dtype, A(AttnProblem, att)),
+                      self._gemm(GEMM_NT, outp),
+                      (ops.ln_fwd, self.dtype, A(LnProblem, ln2), d),
+                      self._gemm(GEMM_NT, fc1),
+                      self._gemm(GEMM_NT, fc2)]
+        fin = [ops.ln_problem(b["x"][c.layers], st.p(e.prefix + "layer_norm.weight"), st.p(e.prefix + "layer_norm.bias"),
+                              b["stf"][0], b["stf"][1], b["R"], out=b["out"], ldo=d, out_f32=True)
+               for e, b in zip(self.encs, self.buf)]
+        steps.append((ops.ln_fwd, self.dtype, A(LnProblem, fin), d))
+        return steps
+
+    _SEEDED = (ops.gemm_grouped, ops.attn_fwd, ops.attn_bwd, ops.rows_cast)
+
+    def _run(self, steps, seed: int) -> None:
+        for s in steps:
+            fn = s[0]
+            if fn is ops.gemm_grouped:
+                fn(s[1], s[2], s[3], seed)
+            elif fn in (ops.attn_fwd, ops.attn_bwd, ops.rows_cast):
+                fn(s[1], s[2], seed)
+            elif fn in (ops.ln_fwd,):
+                fn(s[1], s[2], s[3])
+            elif fn is ops.ln_bwd:
+                fn(s[1], s[2])
+            else:
+                raise RuntimeError("unknown step")
+
+    def forward(self, xq: Sequence[torch.Tensor], xk: Sequence[torch.Tensor], xv: Sequence[torch.Tensor], seed: int,
+                training: bool) -> List[torch.Tensor]:
+        """xq[e]: fp32 [T_e,B,d]; xk[e], xv[e]: fp32 [S_e,B,d] key / value sources (the same tensor at every
+        reference call site, mmtr.py:779-791; they still get independent embedding dropout, transformer.py:73-79)."""
+        c, B, d = self.cfg, self.B, self.cfg.d
+        p = c.embed_dropout if training else 0.0
+        emb = []
+        for e, b, q, k, v in zip(self.encs, self.buf, xq, xk, xv):
+            for t, n in ((q, e.T), (k, e.S), (v, e.S)):
+                if tuple(t.shape) != (n, B, d) or not t.is_contiguous() or t.dtype != torch.float32:
+                    raise ValueError(f"encoder {e.prefix}: expected contiguous fp32 [{n},{B},{d}], got {tuple(t.shape)} {t.dtype}")
+            emb += [ops.embed_problem(q, b["x"][0], e.T, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_Q)),
+                    ops.embed_problem(k, b["ke"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_K)),
+                    ops.embed_problem(v, b["ve"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_V))]
+        ops.embed_pos_fwd(emb, self.table, d, math.sqrt(d), seed)
+        self._run(self._fwd[training], seed)
+        self._last = (seed, training)
+        return [b["out"] for b in self.buf]
+
+    # -- backward tables --------------------------------------------------------
+    def _build_bwd(self, training: bool):
+        c, st, B, d, H = self.cfg, self.store, self.B, self.cfg.d, self.cfg.H
+        ld, ld4, dh, dhp = self.ld, self.ld4, self.dh, self.dhp
+        pr = (lambda p: p) if training else (lambda p: 0.0)
+        A = ops.array
+        G = len(self.encs)
+        steps = []
+        inv_relu = 1.0 / (1.0 - pr(c.relu_dropout))
+        for i in reversed(range(c.layers)):
+            cast2, wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], [], []
+            cast1, wg_att, dg_out, att, csum, dg_q, dg_kv, lnq, lnkv = [], [], [], [], [], [], [], [], []
+            s_cast0, s_dgout0, s_att0, s_csum0, s_wg0, s_dg0a, s_dg0b, s_ln0 = [], [], [], [], [], [], [], []
+            for e, b in zip(self.encs, self.buf):
+                R, Rk = b["R"], b["Rk"]
+                P = lambda leaf: st.p(self._pn(e, i, leaf))
+                GP = lambda leaf, off=0: st.gptr(self._pn(e, i, leaf), off)
+                ipw = self._pn(e, i, "self_attn.in_proj_weight")
+                wo, w1, w2 = (self._pn(e, i, n) for n in ("self_attn.out_proj.weight", "fc1.weight", "fc2.weight"))
+                lnF = 2 if c.biprojection else 1      # FFN LayerNorm index
+                lnK = 1 if c.biprojection else 0      # key/value LayerNorm index
+                stF = (b["st2m"][i], b["st2r"][i]) if c.biprojection else (b["st1m"][i], b["st1r"][i])
+                dx = b["dx"]
+                sk = lambda m, n: _splitk(((m + 127) // 128) * ((n + 63) // 64) * G * 2, R)
+                # ---- FFN
+                cast2.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("fc2.bias"),
+                                              drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES2)))
+                wg_ffn.append(ops.gemm_problem(b["dy"], b["h1"][i], GP("fc2.weight"), d, 4 * d, R, ld, ld4, 4 * d,
+                                               flags=F_ATOMIC, splitk=sk(d, 4 * d)))
+                dg_fc2.append(ops.gemm_problem(b["dy"], st.sptr(w2), b["dh1"], R, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
+                                               gate_scale=inv_relu, colsum=GP("fc1.bias"), out_kind=OUT_CT))
+                wg_ffn.append(ops.gemm_problem(b["dh1"], b["xn2"][i], GP("fc1.weight"), 4 * d, d, R, ld4, ld, d,
+                                               flags=F_ATOMIC, splitk=sk(4 * d, d)))
+                dg_fc1.append(ops.gemm_problem(b["dh1"], st.sptr(w1), b["dxn"], R, d, 4 * d, ld4, ld, d))
+                lnf.append(ops.ln_problem(b["xmid"][i], P(f"layer_norms.{lnF}.weight"), None, stF[0], stF[1], R, dy=b["dxn"], ldy=d,
+                                          add=dx, dx=dx, dgamma=GP(f"layer_norms.{lnF}.weight"), dbeta=GP(f"layer_norms.{lnF}.bias")))
+                # ---- (cross) attention block
+                cast1.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("self_attn.out_proj.bias"),
+                                              drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES1)))
+                wg_att.append(ops.gemm_problem(b["dy"], b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
+                                               flags=F_ATOMIC, splitk=sk(d, d)))
+                dg_out.append(ops.gemm_problem(b["dy"], st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                                               heads=(B, H, e.T, dh, dhp)))
+                att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
+                                            self._mask_off(e.T, e.S), dO=b["dao"], delta=b["delta"], dQ=b["dq"], lddq=ld,
+                                            dK=b["dk"], lddk=ld, dV=b["dv"], lddv=ld, dq_scale=self.scale,
+                                            drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
+                ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
+                for w, src, rows in ((0, b["dq"], R), (1, b["dk"], Rk), (2, b["dv"], Rk)):
+                    csum.append(ops.cast_problem(src, ld, rows, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
+                q_src = b["xq"][i] if c.biprojection else b["xn"][i]
+                for w, dsrc, act, rows in ((0, b["dq"], q_src, R), (1, b["dk"], b["kn"][i], Rk), (2, b["dv"], b["vn"][i], Rk)):
+                    wg_att.append(ops.gemm_problem(dsrc, act, st.gptr(ipw, w * d * d), d, d, rows, ld, ld, d, flags=F_ATOMIC,
+                                                   splitk=_splitk(3 * 5 * G * 4, rows)))
+                if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
+                    dg_q.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
+                else:
+                    dg_q.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
+                    lnq.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R, dy=b["dxn"],
+                                              ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias")))
+                dg_kv.append(ops.gemm_problem(b["dk"], st.sptr(ipw, d * ld), b["dkn"], Rk, d, d, ld, ld, d))
+                dg_kv.append(ops.gemm_problem(b["dv"], st.sptr(ipw, 2 * d * ld), b["dvn"], Rk, d, d, ld, ld, d))
+                gK, dgK, dbK = P(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.bias")
+                lnkv.append(ops.ln_problem(b["ke"], gK, None, b["stkm"][i], b["stkr"][i], Rk, dy=b["dkn"], ldy=d, add=b["dke"],
+                                           dx=b["dke"], dgamma=dgK, dbeta=dbK))
+                lnkv.append(ops.ln_problem(b["ve"], gK, None, b["stvm"][i], b["stvr"][i], Rk, dy=b["dvn"], ldy=d, add=b["dve"],
+                                           dx=b["dve"], dgamma=dgK, dbeta=dbK))
+                if c.biprojection:
+                    # ---- self-attention half (same attention parameters)
+                    s_cast0.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("self_attn.out_proj.bias"),
+                                                    drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
+                    s_wg0.append(ops.gemm_problem(b["dy"], b["aos"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
+                                                  flags=F_ATOMIC, splitk=sk(d, d)))
+                    s_dgout0.append(ops.gemm_problem(b["dy"], st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                                                     heads=(B, H, e.T, dh, dhp)))
+                    s_att0.append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H, e.T, e.T,
+                                                   dh, dhp, self._mask_off(e.T, e.T), dO=b["dao"], delta=b["delta"], dQ=b["dq"],
+                                                   lddq=ld, dK=b["dks"], lddk=ld, dV=b["dvs"], lddv=ld, dq_scale=self.scale,
+                                                   drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
+                    for w, src in ((0, b["dq"]), (1, b["dks"]), (2, b["dvs"])):
+                        s_csum0.append(ops.cast_problem(src, ld, R, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
+                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, ld, ld, d, flags=F_ATOMIC,
+                                                      splitk=_splitk(3 * 5 * G * 4, R)))
+                    s_dg0a.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
+                    s_dg0b.append(ops.gemm_problem(b["dks"], st.sptr(ipw, d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ATOMIC))
+                    s_dg0b.append(ops.gemm_problem(b["dvs"], st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ATOMIC))
+                    s_ln0.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R,
+                                                dy=b["dxn"], ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"),
+                                                dbeta=GP("layer_norms.0.bias")))
+            steps += [(ops.rows_cast, self.dtype, A(CastProblem, cast2)),
+                      self._gemm(GEMM_NN, dg_fc2),
+                      self._gemm(GEMM_TN, wg_ffn),
+                      self._gemm(GEMM_NN, dg_fc1),
+                      (ops.ln_bwd, A(LnProblem, lnf), d),
+                      (ops.rows_cast, self.dtype, A(CastProblem, cast1)),
+                      self._gemm(GEMM_NN, dg_out),
+                      (ops.attn_bwd, self.dtype, A(AttnProblem, att)),
+                      (ops.rows_cast, self.dtype, A(CastProblem, csum)),
+                      self._gemm(GEMM_TN, wg_att),
+                      self._gemm(GEMM_NN, dg_q + dg_kv)]
+            if lnq:
+                steps.append((ops.ln_bwd, A(LnProblem, lnq + lnkv), d))
+            else:
+                steps.append((ops.ln_bwd, A(LnProblem, lnkv), d))
+            if c.biprojection:
+                steps += [(ops.rows_cast, self.dtype, A(CastProblem, s_cast0)),
+                          self._gemm(GEMM_NN, s_dgout0),
+                          (ops.attn_bwd, self.dtype, A(AttnProblem, s_att0)),
+                          (ops.rows_cast, self.dtype, A(CastProblem, s_csum0)),
+                          self._gemm(GEMM_TN, s_wg0),
+                          self._gemm(GEMM_NN, s_dg0a),
+                          self._gemm(GEMM_NN, s_dg0b),
+                          (ops.ln_bwd, A(LnProblem, s_ln0), d)]
+        return steps
+
+    def backward(self, douts: Sequence[Optional[torch.Tensor]]):
+        """douts[e]: fp32 [T_e,B,d] gradient of encoder e's output (None = zero).  Returns the plan-owned
+        gradients w.r.t. each encoder's query, key and value sources (three lists), and accumulates
+        parameter gradients into the ParamStore's flat gradient buffer."""
+        seed, training = self._last
+        c, st, B, d = self.cfg, self.store, self.B, self.cfg.d
+        fin, keep = [], []
+        for e, b, g in zip(self.encs, self.buf, douts):
+            b["dke"].zero_()
+            b["dve"].zero_()
+            if g is None:
+                b["dx"].zero_()
+                continue
+            g = g.contiguous()
+            keep.append(g)
+            fin.append(ops.ln_problem(b["x"][c.layers], st.p(e.prefix + "layer_norm.weight"), None, b["stf"][0], b["stf"][1], b["R"],
+                                      dy=g, ldy=d, dx=b["dx"], dgamma=st.gptr(e.prefix + "layer_norm.weight"),
+                                      dbeta=st.gptr(e.prefix + "layer_norm.bias")))
+        if fin:
+            ops.ln_bwd(fin, d)
+        self._run(self._bwd[training], seed)
+        p = c.embed_dropout if training else 0.0
+        emb = []
+        for e, b in zip(self.encs, self.buf):
+            emb.append(ops.embed_problem(b["dx"], b["dxq"], e.T, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_Q)))
+            emb.append(ops.embed_problem(b["dke"], b["dxk"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_K)))
+            emb.append(ops.embed_problem(b["dve"], b["dxv"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_V)))
+        ops.embed_pos_bwd(emb, d, math.sqrt(d), seed)
+        return [b["dxq"] for b in self.buf], [b["dxk"] for b in self.buf], [b["dxv"] for b in self.buf]
+
+
+def register_encoder_shadows(store: ParamStore, prefix: str, d: int, layers: int) -> None:
+    for i in range(layers):
+        p = f"{prefix}layers.{i}."
+        store.add_shadow(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_weight", 3 * d, d)
+        store.add_shadow(p + "self_attn.out_proj.weight", p + "self_attn.out_proj.weight", d, d)
+        store.add_shadow(p + "fc1.weight", p + "fc1.weight", 4 * d, d)
+        store.add_shadow(p + "fc2.weight", p + "fc2.weight", d, 4 * d)

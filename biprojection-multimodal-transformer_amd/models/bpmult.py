@@ -1,0 +1,557 @@
+"""BPMulT model graphs on the MI355X engine.
+
+`MultiprojectionMMTransformer3DGMUClf` (3-modal, reference mmtr.py:587-866) and
+`MultiprojectionMMTransformerGMUClf` (4-modal, mmtr.py:277-583) keep the
+reference's constructor (`args`), forward signature and state_dict names.  The
+hot path -- temporal 1x1 projections, the twelve crossmodal / biprojection
+encoders, the dense Fusion-GMU layers, the time-axis maps -- runs as grouped
+HIP launches orchestrated by `_Trunk`; what the path hands to PyTorch is six
+[N,B,d] tensors (GMU "top" and "middle" per target modality).  The [B,d]-sized
+tail (token pick, final n-way GMU, residual head) and the front-ends upstream
+of the path (text encoder, AudioEncoder, poster projection) are ordinary
+PyTorch-ROCm modules.
+
+Deliberate departures from the reference's *behaviour as shipped* (all listed
+in SURVEY.md section 0): the 3-modal final GMU takes three inputs (the
+reference's 4-argument call to a 5-argument constructor cannot be built);
+zero-padding is device agnostic; `--hybrid` is not supported (broken upstream).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import config, ops
+from .._lib import BPM_F32, F_ATOMIC, GEMM_NN, GEMM_NT, GEMM_TN, OUT_F32, CastProblem, GemmProblem, GmuProblem
+from ..engine import (SITE_TEXT, EncoderDesc, EncoderGroupPlan, GroupCfg, ParamStore, _splitk, register_encoder_shadows)
+from ..ops import pad32
+from .encoder import TransformerEncoder
+
+# encoder name -> (query modality, key/value source, attention-dropout key = last letter of the reference tag)
+LEVEL1 = {"trans_v_with_a": ("v", "a", "a"), "trans_a_with_v": ("a", "v", "v"), "trans_v_with_l": ("v", "l", "l"),
+          "trans_l_with_v": ("l", "v", "v"), "trans_a_with_l": ("a", "l", "l"), "trans_l_with_a": ("l", "a", "a")}
+# level 2: key/value source is a level-1 OUTPUT (mmtr.py:790-791, 812-813, 834-835)
+LEVEL2 = {"trans_l_with_v2a": ("l", "trans_a_with_v", "a"), "trans_l_with_a2v": ("l", "trans_v_with_a", "v"),
+          "trans_a_with_v2l": ("a", "trans_l_with_v", "l"), "trans_a_with_l2v": ("a", "trans_v_with_l", "v"),
+          "trans_v_with_a2l": ("v", "trans_l_with_a", "l"), "trans_v_with_l2a": ("v", "trans_a_with_l", "a")}
+# fusion per target modality: (lvl2_a, lvl1_a, lvl2_b, lvl1_b); the middle GMU takes (lvl1_a, lvl1_b)
+# (argument order of mmtr.py:796-803, 818-825, 840-847)
+FUSE = {"l": ("trans_l_with_a2v", "trans_v_with_a", "trans_l_with_v2a", "trans_a_with_v"),
+        "a": ("trans_a_with_v2l", "trans_l_with_v", "trans_a_with_l2v", "trans_v_with_l"),
+        "v": ("trans_v_with_a2l", "trans_l_with_a", "trans_v_with_l2a", "trans_a_with_l")}
+# 4-modal: level-1 outputs whose length differs from the target's go through a time-axis Linear (mmtr.py:507-508,530,553)
+TIME_MAP = {"l": {"trans_v_with_a": "transfm_v2l", "trans_a_with_v": "transfm_a2l"},
+            "a": {"trans_l_with_v": "transfm_l2a"},
+            "v": {"trans_l_with_a": "transfm_l2v"}}
+ENC_ORDER = list(LEVEL1) + list(LEVEL2)
+
+
+class GatedMultimodalLayerFeatures(nn.Module):
+    """Fusion-GMU parameters (mmtr.py:179-188); evaluated by the trunk."""
+
+    def __init__(self, size_in1, size_in2, size_out):
+        super().__init__()
+        self.hidden1 = nn.Linear(size_in1, size_out, bias=False)
+        self.hidden2 = nn.Linear(size_in2, size_out, bias=False)
+        self.x_gate = nn.Linear(size_in1 + size_in2, size_out, bias=False)
+
+
+class TextShiftingLayer(nn.Module):
+    """n-way gated fusion on [B,d] rows (TextShifting3Layer / TextShifting4Layer,
+    mmtr.py:197-247): sum_i sigmoid(G_i [x_1|..|x_n]) * tanh(W_i x_i)."""
+
+    def __init__(self, sizes_in: Sequence[int], size_out: int):
+        super().__init__()
+        tot = sum(sizes_in)
+        for i, s in enumerate(sizes_in, 1):
+            setattr(self, f"hidden{i}", nn.Linear(s, size_out, bias=False))
+            setattr(self, f"x{i}_gate", nn.Linear(tot, size_out, bias=False))
+        self.n = len(sizes_in)
+
+    def forward(self, xs):
+        cat = torch.cat(xs, dim=-1)
+        out, zs = 0, []
+        for i, x in enumerate(xs, 1):
+            z = torch.sigmoid(getattr(self, f"x{i}_gate")(cat))
+            out = out + z * torch.tanh(getattr(self, f"hidden{i}")(x))
+            zs.append(z)
+        return out, torch.cat(zs, dim=-1)
+
+
+class AudioEncoder(nn.Module):
+    """Front-end of the 4-modal model (mmtr.py:93-108); upstream of the hot path."""
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.conv_layers = nn.ModuleList([nn.Conv1d(96, 96, 128, stride=2), nn.Conv1d(96, 96, 128, stride=2),
+                                          nn.AdaptiveAvgPool1d(200)])
+
+    def forward(self, x):
+        for layer in self.conv_layers:
+            x = layer(x)
+        return x
+
+
+class BertEncoder(nn.Module):
+    """Text encoder plug point (mmtr.py:144-158).  `args.bert_model` may be a local
+    HF directory; with `args.text_features=True` (synthetic benchmarks, parity
+    tests) the `txt` argument already holds [B,L,orig_d_l] features."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.features_in = bool(getattr(args, "text_features", False))
+        self.bert = None
+        if not self.features_in:
+            from transformers import BertModel  # local directory only: there is no network
+            self.bert = BertModel.from_pretrained(args.bert_model)
+
+    def forward(self, txt, mask, segment):
+        if self.features_in:
+            return txt
+        return self.bert(input_ids=txt, token_type_ids=segment, attention_mask=mask, return_dict=False)[0]
+
+
+# ----------------------------------------------------------------------------
+class _Trunk:
+    """Device buffers + launch tables of the hot path for one batch size."""
+
+    def __init__(self, model: "_BPMulTBase", B: int):
+        self.m, self.B = model, B
+        st = model._store
+        self.st, self.dtype = st, st.dtype
+        d = model.d
+        self.d, self.ld = d, pad32(d)
+        dev = st.device
+        ct = ops.ct_torch(self.dtype)
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
+        self.N = {"l": model.num_vectors_l, "a": model.num_vectors_a, "v": model.num_vectors_v}
+        self.px = {k: z(n, B, d) for k, n in self.N.items()}            # projected, zero-padded inputs [N,B,d]
+        self.dpx = {k: z(n, B, d) for k, n in self.N.items()}
+        cfg1 = GroupCfg(d, model.num_heads, model.layers, model.relu_dropout, model.res_dropout, model.embed_dropout,
+                        model.attn_mask, False)
+        cfg2 = GroupCfg(d, model.num_heads, model.layers, model.relu_dropout, model.res_dropout, model.embed_dropout,
+                        model.attn_mask, model.four_modal)
+        adrop = {"l": model.attn_dropout, "a": model.attn_dropout_a, "v": model.attn_dropout_v}
+        e1 = [EncoderDesc(n + ".", ENC_ORDER.index(n), self.N[q], self.N[kv], adrop[key]) for n, (q, kv, key) in LEVEL1.items()]
+        e2 = [EncoderDesc(n + ".", ENC_ORDER.index(n), self.N[q], self.N[LEVEL1[src][0]], adrop[key])
+              for n, (q, src, key) in LEVEL2.items()]
+        self.plan1 = EncoderGroupPlan(st, cfg1, e1, B)
+        self.plan2 = EncoderGroupPlan(st, cfg2, e2, B)
+        self.out1 = {n: b["out"] for n, b in zip(LEVEL1, self.plan1.buf)}
+        self.out2 = {n: b["out"] for n, b in zip(LEVEL2, self.plan2.buf)}
+        # ---- time-axis maps (4-modal only)
+        self.tmap: Dict[Tuple[str, str], dict] = {}
+        if model.four_modal:
+            BD = B * d
+            ldbd = pad32(BD)
+            for tgt, maps in TIME_MAP.items():
+                for src_name, lin in maps.items():
+                    Ts, Td = self.N[LEVEL1[src_name][0]], self.N[tgt]
+                    self.tmap[(tgt, src_name)] = dict(lin=lin, Ts=Ts, Td=Td, ldbd=ldbd, h_ct=z(Ts, ldbd, dt=ct), out=z(Td, B, d),
+                                                      dout=z(Td, B, d), dout_ct=z(Td, ldbd, dt=ct), dh=z(Ts, B, d))
+            self.ones_bd = torch.ones(1, ldbd, device=dev, dtype=ct)
+            self.ones_bd[:, BD:] = 0
+        # ---- dense Fusion-GMU layers: per target modality a "middle" and a "top" unit
+        self.g: Dict[Tuple[str, str], dict] = {}
+        for tgt in ("l", "a", "v"):
+            R = self.N[tgt] * B
+            for kind in ("mid", "top"):
+                self.g[(tgt, kind)] = dict(R=R, x1=z(R, d), x2=z(R, d), xc=z(R, 2 * self.ld, dt=ct), a1=z(R, d), a2=z(R, d),
+                                           ag=z(R, d), out=z(self.N[tgt], B, d), da1=z(R, self.ld, dt=ct),
+                                           da2=z(R, self.ld, dt=ct), dag=z(R, self.ld, dt=ct), dx1=z(R, d), dx2=z(R, d))
+        self._build_gmu()
+        self._conv_cache = {}
+
+    # -- temporal 1x1 projections (mmtr.py:456-469 / 748-761) -----------------------
+    def conv_forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> None:
+        """feats[m]: fp32 [B,T_m,orig_d_m] contiguous.  Fills px[m] = zero-padded [N_m,B,d]."""
+        m, B, d, st = self.m, self.B, self.d, self.st
+        packs_ct, packs_f32, gemms = [], [], []
+        self._conv = {}
+        for k in ("l", "a", "v"):
+            x = feats[k]
+            T, od = x.shape[1], x.shape[2]
+            if T > self.N[k]:
+                raise ValueError(f"modality {k}: sequence length {T} exceeds num_vectors_{k}={self.N[k]}")
+            p = m.embed_dropout if (training and k == "l") else 0.0           # text-feature dropout, mmtr.py:741
+            px = self.px[k]
+            if T < self.N[k]:
+                px[T:].zero_()
+            if od == d:                                                        # projection skipped (mmtr.py:748-750)
+                packs_f32.append(ops.pack_problem(B, T, od, d, src=x, dst=px, drop_p=p, drop_site=SITE_TEXT))
+                self._conv[k] = dict(T=T, od=od, x=x, p=p, packed=None)
+                continue
+            kp = pad32(od)
+            key = (k, T)
+            if key not in self._conv_cache:
+                self._conv_cache[key] = dict(packed=torch.zeros(T * B, kp, device=st.device, dtype=ops.ct_torch(self.dtype)),
+                                             dy=torch.zeros(T * B, self.ld, device=st.device, dtype=ops.ct_torch(self.dtype)),
+                                             dpk=torch.zeros(T * B, od, device=st.device))
+            cc = self._conv_cache[key]
+            packs_ct.append(ops.pack_problem(B, T, od, kp, src=x, dst=cc["packed"], drop_p=p, drop_site=SITE_TEXT))
+            gemms.append(ops.gemm_problem(cc["packed"], st.sptr(f"proj_{k}.weight"), px, T * B, d, od, kp, kp, d))
+            self._conv[k] = dict(T=T, od=od, x=x, p=p, **cc)
+        if packs_f32:
+            ops.pack_rows_fwd(BPM_F32, packs_f32, seed)
+        if packs_ct:
+            ops.pack_rows_fwd(self.dtype, packs_ct, seed)
+            ops.gemm_grouped(self.dtype, GEMM_NT, gemms, seed)
+
+    def conv_backward(self, seed: int, need_dx: Dict[str, bool]) -> Dict[str, Optional[torch.Tensor]]:
+        """Consumes dpx[m]; accumulates proj_m.weight gradients; returns d(feats[m]) where requested."""
+        B, d, st = self.B, self.d, self.st
+        casts, wg, dg, unpack = [], [], [], []
+        res: Dict[str, Optional[torch.Tensor]] = {"l": None, "a": None, "v": None}
+        for k, c in self._conv.items():
+            T, od = c["T"], c["od"]
+            R = T * B
+            if c["packed"] is None:
+                if need_dx[k]:
+                    res[k] = torch.empty_like(c["x"])
+                    unpack.append(ops.pack_problem(B, T, od, 0, g=self.dpx[k], ldg=d, dsrc=res[k], drop_p=c["p"], drop_site=SITE_TEXT))
+                continue
+            kp = pad32(od)
+            casts.append(ops.cast_problem(self.dpx[k], d, R, d, dst_ct=c["dy"], ldd=self.ld))
+            wg.append(ops.gemm_problem(c["dy"], c["packed"], st.gptr(f"proj_{k}.weight"), d, od, R, self.ld, kp, od,
+                                       flags=F_ATOMIC, splitk=_splitk(6, R)))
+            if need_dx[k]:
+                res[k] = torch.empty_like(c["x"])
+                dg.append(ops.gemm_problem(c["dy"], st.sptr(f"proj_{k}.weight"), c["dpk"], R, od, d, self.ld, kp, od))
+                unpack.append(ops.pack_problem(B, T, od, 0, g=c["dpk"], ldg=od, dsrc=res[k], drop_p=c["p"], drop_site=SITE_TEXT))
+        if casts:
+            ops.rows_cast(self.dtype, casts, seed)
+            ops.gemm_grouped(self.dtype, GEMM_TN, wg, seed)
+        if dg:
+            ops.gemm_grouped(self.dtype, GEMM_NN, dg, seed)
+        if unpack:
+            ops.pack_rows_bwd(unpack, seed)
+        return res
+
+    # -- time-axis Linear (4-modal) --------------------------------------------------
+    def _time_forward(self) -> None:
+        if not self.tmap:
+            return
+        B, d, st = self.B, self.d, self.st
+        BD = B * d
+        casts, gemms = [], []
+        for (tgt, src), t in self.tmap.items():
+            casts.append(ops.cast_problem(self.out1[src], BD, t["Ts"], BD, dst_ct=t["h_ct"], ldd=t["ldbd"]))
+            gemms.append(ops.gemm_problem(st.sptr(t["lin"] + ".weight"), t["h_ct"], t["out"], t["Td"], BD, t["Ts"], pad32(t["Ts"]),
+                                          t["ldbd"], BD, bias_m=st.p(t["lin"] + ".bias")))
+        ops.rows_cast(self.dtype, casts, 0)
+        ops.gemm_grouped(self.dtype, GEMM_NN, gemms, 0)
+
+    def _time_backward(self) -> None:
+        """dout (fp32 [Td,B,d]) of every map -> weight / bias gradients and dh (fp32 [Ts,B,d])."""
+        if not self.tmap:
+            return
+        B, d, st = self.B, self.d, self.st
+        BD = B * d
+        casts, wg, dg = [], [], []
+        for (tgt, src), t in self.tmap.items():
+            casts.append(ops.cast_problem(t["dout"], BD, t["Td"], BD, dst_ct=t["dout_ct"], ldd=t["ldbd"]))
+            wg.append(ops.gemm_problem(t["dout_ct"], t["h_ct"], st.gptr(t["lin"] + ".weight"), t["Td"], t["Ts"], BD, t["ldbd"], t["ldbd"],
+                                       t["Ts"], flags=F_ATOMIC, splitk=_splitk(16, BD)))
+            wg.append(ops.gemm_problem(t["dout_ct"], self.ones_bd, st.gptr(t["lin"] + ".bias"), t["Td"], 1, BD, t["ldbd"], t["ldbd"], 1,
+                                       flags=F_ATOMIC, splitk=_splitk(16, BD)))
+            dg.append(ops.gemm_problem(st.sptr(t["lin"] + ".weight"), t["dout_ct"], t["dh"], t["Ts"], BD, t["Td"], pad32(t["Ts"]),
+                                       t["ldbd"], BD))
+        ops.rows_cast(self.dtype, casts, 0)
+        ops.gemm_grouped(self.dtype, GEMM_NT, wg, 0)
+        ops.gemm_grouped(self.dtype, GEMM_TN, dg, 0)
+
+    # -- dense Fusion-GMU -------------------------------------------------------------
+    def _lvl1(self, tgt: str, name: str) -> torch.Tensor:
+        """Level-1 output as the fusion of target `tgt` sees it (through the time map in the 4-modal model)."""
+        t = self.tmap.get((tgt, name))
+        return t["out"] if t is not None else self.out1[name]
+
+    def _build_gmu(self) -> None:
+        B, d, ld, st = self.B, self.d, self.ld, self.st
+        A = ops.array
+        casts, gemms, gates = [], [], []
+        bw_gate, bw_wg, bw_dg = [], [], []
+        for tgt in ("l", "a", "v"):
+            l2a, l1a, l2b, l1b = FUSE[tgt]
+            xa, xb = self._lvl1(tgt, l1a), self._lvl1(tgt, l1b)
+            for kind, pfx in (("mid", f"gmu_{tgt}_m."), ("top", f"gmu_{tgt}.")):
+                g = self.g[(tgt, kind)]
+                R = g["R"]
+                xc1, xc2 = g["xc"], g["xc"][:, ld:]
+                if kind == "mid":
+                    casts.append(ops.cast_problem(xa, d, R, d, dst_ct=xc1, ldd=2 * ld, ct_cols=ld, dst_f32=g["x1"], ldf=d))
+                    casts.append(ops.cast_problem(xb, d, R, d, dst_ct=xc2, ldd=2 * ld, ct_cols=ld, dst_f32=g["x2"], ldf=d))
+                else:                                                       # level 1 -> 2 residual, mmtr.py:799-800
+                    casts.append(ops.cast_problem(self.out2[l2a], d, R, d, b=xa, ldb=d, dst_ct=xc1, ldd=2 * ld, ct_cols=ld, dst_f32=g["x1"], ldf=d))
+                    casts.append(ops.cast_problem(self.out2[l2b], d, R, d, b=xb, ldb=d, dst_ct=xc2, ldd=2 * ld, ct_cols=ld, dst_f32=g["x2"], ldf=d))
+                w1, w2, wg_ = pfx + "hidden1.weight", pfx + "hidden2.weight", pfx + "x_gate.weight"
+                gemms.append(ops.gemm_problem(xc1, st.sptr(w1), g["a1"], R, d, d, 2 * ld, ld, d))
+                gemms.append(ops.gemm_problem(xc2, st.sptr(w2), g["a2"], R, d, d, 2 * ld, ld, d))
+                gemms.append(ops.gemm_problem(xc1, st.sptr(wg_), g["ag"], R, d, 2 * ld, 2 * ld, 2 * ld, d))
+                gates.append(ops.gmu_problem(g["a1"], g["a2"], g["ag"], g["x1"], g["x2"], R, out=g["out"]))
+                g["dout"] = torch.zeros(self.N[tgt], B, d, device=st.device)
+                bw_gate.append(ops.gmu_problem(g["a1"], g["a2"], g["ag"], g["x1"], g["x2"], R, dout=g["dout"], da1=g["da1"], da2=g["da2"],
+                                               dag=g["dag"], ldg=ld, dx1=g["dx1"], dx2=g["dx2"]))
+                sk = _splitk(24 * 25, R)
+                bw_wg += [ops.gemm_problem(g["da1"], xc1, st.gptr(w1), d, d, R, ld, 2 * ld, d, flags=F_ATOMIC, splitk=sk),
+                          ops.gemm_problem(g["da2"], xc2, st.gptr(w2), d, d, R, ld, 2 * ld, d, flags=F_ATOMIC, splitk=sk),
+                          ops.gemm_problem(g["dag"], xc1, st.gptr(wg_), d, d, R, ld, 2 * ld, 2 * d, flags=F_ATOMIC, splitk=sk),
+                          ops.gemm_problem(g["dag"], xc2, st.gptr(wg_, d), d, d, R, ld, 2 * ld, 2 * d, flags=F_ATOMIC, splitk=sk)]
+                # dx1 / dx2 already hold the direct terms; the linear paths are added atomically
+                bw_dg += [ops.gemm_problem(g["da1"], st.sptr(w1), g["dx1"], R, d, d, ld, ld, d, flags=F_ATOMIC),
+                          ops.gemm_problem(g["dag"], st.sptr(wg_), g["dx1"], R, d, d, ld, 2 * ld, d, flags=F_ATOMIC),
+                          ops.gemm_problem(g["da2"], st.sptr(w2), g["dx2"], R, d, d, ld, ld, d, flags=F_ATOMIC),
+                          ops.gemm_problem(g["dag"], st.sptr(wg_, ld), g["dx2"], R, d, d, ld, 2 * ld, d, flags=F_ATOMIC)]
+        self._gmu_fwd = (A(CastProblem, casts), A(GemmProblem, gemms), A(GmuProblem, gates))
+        self._gmu_bwd = (A(GmuProblem, bw_gate), A(GemmProblem, bw_wg), A(GemmProblem, bw_dg))
+
+    def gmu_forward(self) -> None:
+        casts, gemms, gates = self._gmu_fwd
+        ops.rows_cast(self.dtype, casts, 0)
+        ops.gemm_grouped(self.dtype, GEMM_NT, gemms, 0)
+        ops.gmu2_fwd(gates, self.d)
+
+    def gmu_backward(self) -> None:
+        gate, wg, dg = self._gmu_bwd
+        ops.gmu2_bwd(self.dtype, gate, self.d)
+        ops.gemm_grouped(self.dtype, GEMM_TN, wg, 0)
+        ops.gemm_grouped(self.dtype, GEMM_NN, dg, 0)
+
+    # -- whole trunk ------------------------------------------------------------------
+    def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> List[torch.Tensor]:
+        self.st.refresh_shadows()
+        self.conv_forward(feats, seed, training)
+        px = self.px
+        q1 = [px[q] for (q, kv, _) in LEVEL1.values()]
+        k1 = [px[kv] for (q, kv, _) in LEVEL1.values()]
+        self.plan1.forward(q1, k1, k1, seed, training)
+        q2 = [px[q] for (q, src, _) in LEVEL2.values()]
+        k2 = [self.out1[src] for (q, src, _) in LEVEL2.values()]
+        self.plan2.forward(q2, k2, k2, seed, training)
+        self._time_forward()
+        self.gmu_forward()
+        return [self.g[(t, k)]["out"] for t in ("l", "a", "v") for k in ("top", "mid")]
+
+    def backward(self, grads: Sequence[Optional[torch.Tensor]], seed: int, need_dx: Dict[str, bool]):
+        """grads: d(top_l), d(mid_l), d(top_a), d(mid_a), d(top_v), d(mid_v)."""
+        st = self.st
+        st.begin_backward()
+        it = iter(grads)
+        for t in ("l", "a", "v"):
+            for k in ("top", "mid"):
+                g = next(it)
+                if g is None:
+                    self.g[(t, k)]["dout"].zero_()
+                else:
+                    self.g[(t, k)]["dout"].copy_(g)
+        self.gmu_backward()
+        # gradient of every level-2 output (top GMU operand) and level-1 output (middle + top GMU operands)
+        d2: Dict[str, torch.Tensor] = {}
+        d1: Dict[str, torch.Tensor] = {}
+        dtm: Dict[Tuple[str, str], torch.Tensor] = {}
+        for tgt in ("l", "a", "v"):
+            l2a, l1a, l2b, l1b = FUSE[tgt]
+            top, mid = self.g[(tgt, "top")], self.g[(tgt, "mid")]
+            shp = (self.N[tgt], self.B, self.d)
+            d2[l2a], d2[l2b] = top["dx1"].view(shp), top["dx2"].view(shp)
+            for name, gsum in ((l1a, top["dx1"] + mid["dx1"]), (l1b, top["dx2"] + mid["dx2"])):
+                if (tgt, name) in self.tmap:
+                    self.tmap[(tgt, name)]["dout"].copy_(gsum.view(shp))
+                else:
+                    d1[name] = gsum.view(shp)
+        self._time_backward()
+        for (tgt, name), t in self.tmap.items():
+            d1[name] = t["dh"]
+        dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2])
+        for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
+            d1[src] = d1[src] + gk + gv
+        dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1])
+        acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
+        for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
+            acc[q].append(gq)
+            acc[kv] += [gk, gv]
+        for (n, (q, src, _)), gq in zip(LEVEL2.items(), dq2):
+            acc[q].append(gq)
+        for k, terms in acc.items():
+            torch.sum(torch.stack(terms), dim=0, out=self.dpx[k])
+        res = self.conv_backward(seed, need_dx)
+        st.end_backward()
+        return res
+
+
+class _TrunkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x_l, x_v, x_a, model):
+        trunk = model._trunk_for(x_l.shape[0])
+        seed = model._next_seed()
+        feats = {"l": x_l.detach().contiguous(), "v": x_v.detach().contiguous(), "a": x_a.detach().contiguous()}
+        outs = trunk.forward(feats, seed, model.training)
+        ctx.trunk, ctx.seed = trunk, seed
+        ctx.need = {"l": x_l.requires_grad, "v": x_v.requires_grad, "a": x_a.requires_grad}
+        return tuple(o.detach().clone() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        res = ctx.trunk.backward(grads, ctx.seed, ctx.need)
+        return None, res["l"], res["v"], res["a"], None
+
+
+class _BPMulTBase(nn.Module):
+    four_modal = False
+
+    def _init_common(self, args):
+        self.args = args
+        self.orig_d_l, self.orig_d_v, self.orig_d_a = args.orig_d_l, args.orig_d_v, args.orig_d_a
+        self.d = self.d_l = self.d_a = self.d_v = args.hidden_sz
+        self.vonly, self.lonly, self.aonly = args.vonly, args.lonly, args.aonly
+        if not (self.vonly and self.lonly and self.aonly):
+            raise NotImplementedError("the hot path is built for the full model (lonly = vonly = aonly = True, the default)")
+        if getattr(args, "hybrid", False):
+            raise NotImplementedError("--hybrid is broken in the reference (SURVEY.md section 0) and outside the hot path")
+        self.num_heads, self.layers = args.num_heads, args.layers
+        self.attn_dropout, self.attn_dropout_v, self.attn_dropout_a = args.attn_dropout, args.attn_dropout_v, args.attn_dropout_a
+        self.relu_dropout, self.res_dropout = args.relu_dropout, args.res_dropout
+        self.out_dropout, self.embed_dropout, self.attn_mask = args.out_dropout, args.embed_dropout, args.attn_mask
+        self.precision: Optional[str] = getattr(args, "precision", None)
+        d = self.d
+        self.enc = BertEncoder(args)
+        for t in ("l", "v", "a"):
+            setattr(self, f"gmu_{t}_m", GatedMultimodalLayerFeatures(d, d, d))
+        for t in ("l", "v", "a"):
+            setattr(self, f"gmu_{t}", GatedMultimodalLayerFeatures(d, d, d))
+        self.proj_l = nn.Conv1d(self.orig_d_l, d, kernel_size=1, padding=0, bias=False)
+        self.proj_v = nn.Conv1d(self.orig_d_v, d, kernel_size=1, padding=0, bias=False)
+        self.proj_a = nn.Conv1d(self.orig_d_a, d, kernel_size=1, padding=0, bias=False)
+        tag_drop = {"l": self.attn_dropout, "a": self.attn_dropout_a, "v": self.attn_dropout_v}
+        order = ["trans_l_with_a", "trans_l_with_v", "trans_l_with_v2a", "trans_l_with_a2v",
+                 "trans_v_with_l", "trans_v_with_a", "trans_v_with_l2a", "trans_v_with_a2l",
+                 "trans_a_with_l", "trans_a_with_v", "trans_a_with_v2l", "trans_a_with_l2v"]       # reference registration order
+        for n in order:
+            key = (LEVEL1.get(n) or LEVEL2.get(n))[2]
+            setattr(self, n, TransformerEncoder(d, self.num_heads, self.layers, attn_dropout=tag_drop[key],
+                                                relu_dropout=self.relu_dropout, res_dropout=self.res_dropout,
+                                                embed_dropout=self.embed_dropout, attn_mask=self.attn_mask,
+                                                biprojection=self.four_modal and n in LEVEL2))
+        self.proj1, self.proj2 = nn.Linear(d, d), nn.Linear(d, d)
+        self.out_layer = nn.Linear(d, args.n_classes)
+        self._store: Optional[ParamStore] = None
+        self._trunks: Dict[int, _Trunk] = {}
+        self._step = 0
+
+    def _init_time_maps(self):
+        L, A, V = self.num_vectors_l, self.num_vectors_a, self.num_vectors_v
+        self.transfm_a2l, self.transfm_v2l = nn.Linear(A, L), nn.Linear(V, L)
+        self.transfm_l2a, self.transfm_l2v = nn.Linear(L, A), nn.Linear(L, V)
+
+    # -- engine plumbing -------------------------------------------------------------
+    TAIL = ("enc.", "audio_enc.", "proj_poster.", "gmu.", "proj1.", "proj2.", "out_layer.")
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._store, self._trunks = None, {}
+        return r
+
+    def _ensure_store(self) -> ParamStore:
+        if self._store is None or not self._store.still_flat():
+            named = [(n, p) for n, p in self.named_parameters() if not n.startswith(self.TAIL)]
+            dt = config.dtype_code(self.precision or config.precision())
+            st = ParamStore(named, dt)
+            d = self.d
+            for n in ENC_ORDER:
+                register_encoder_shadows(st, n + ".", d, self.layers)
+            for k, od in (("l", self.orig_d_l), ("v", self.orig_d_v), ("a", self.orig_d_a)):
+                st.add_shadow(f"proj_{k}.weight", f"proj_{k}.weight", d, od)
+            ld = pad32(d)
+            for t in ("l", "v", "a"):
+                for pfx in (f"gmu_{t}_m.", f"gmu_{t}."):
+                    st.add_shadow(pfx + "hidden1.weight", pfx + "hidden1.weight", d, d)
+                    st.add_shadow(pfx + "hidden2.weight", pfx + "hidden2.weight", d, d)
+                    # x_gate [d, 2d] -> [d, 2*ld]: each half padded on its own so it lines up with [x1 | x2]
+                    st.add_shadow(pfx + "x_gate.weight", pfx + "x_gate.weight", d, d, src_ld=2 * d, dst_ld=2 * ld)
+                    st.add_shadow(pfx + "x_gate.weight#2", pfx + "x_gate.weight", d, d, src_col0=d, src_ld=2 * d, dst_ld=2 * ld,
+                                  dst_col0=ld, base_key=pfx + "x_gate.weight")
+            if self.four_modal:
+                for lin in ("transfm_a2l", "transfm_v2l", "transfm_l2a", "transfm_l2v"):
+                    w = getattr(self, lin).weight
+                    st.add_shadow(lin + ".weight", lin + ".weight", w.shape[0], w.shape[1])
+            st.finalize_shadows()
+            self._store, self._trunks = st, {}
+            self._anchor = torch.zeros(1, device=st.device, requires_grad=True)
+        return self._store
+
+    def _trunk_for(self, B: int) -> _Trunk:
+        self._ensure_store()
+        if B not in self._trunks:
+            self._trunks[B] = _Trunk(self, B)
+        return self._trunks[B]
+
+    def _next_seed(self) -> int:
+        self._step += 1
+        return (torch.initial_seed() * 1000003 + self._step) & 0xFFFFFFFFFFFFFFFF
+
+    def _fuse_and_head(self, outs, extra):
+        """[B,d]-sized tail: level 1->3 residual + first/last token (mmtr.py:806-808), final GMU, residual head."""
+        top_l, mid_l, top_a, mid_a, top_v, mid_v = outs
+        last = []
+        for top, mid in ((top_l, mid_l), (top_v, mid_v), (top_a, mid_a)):       # order (l, v, a), mmtr.py:857
+            tot = top + mid
+            last.append(tot[0] + tot[-1])
+        last_hs, z = self.gmu(last + extra)
+        y = self.proj2(F.dropout(F.relu(self.proj1(last_hs)), p=self.out_dropout, training=self.training)) + last_hs
+        return self.out_layer(y), z
+
+    def _trunk(self, x_l, x_v, x_a):
+        self._ensure_store()
+        return _TrunkFn.apply(self._anchor, x_l.float(), x_v.float(), x_a.float(), self)
+
+
+class MultiprojectionMMTransformer3DGMUClf(_BPMulTBase):
+    """3-modal BPMulT (text, video, audio).  forward(txt, mask, segment, img, audio, output_gate=False)."""
+    four_modal = False
+
+    def __init__(self, args):
+        super().__init__()
+        self._init_common(args)
+        d = self.d
+        self.gmu = TextShiftingLayer([d, d, d], d)
+        # sequence lengths are source constants in the reference (mmtr.py:664-670); overridable here
+        self.num_vectors_l = getattr(args, "num_vectors_l", 512)
+        self.num_vectors_a = getattr(args, "num_vectors_a", 512)
+        self.num_vectors_v = getattr(args, "num_vectors_v", 512)
+        self._init_time_maps()            # present in the state_dict, unused by the 3-modal graph (mmtr.py:794-795)
+
+    def forward(self, txt, mask, segment, img, audio, output_gate=False):
+        x_l = self.enc(txt, mask, segment)                     # [B,L,orig_d_l]
+        outs = self._trunk(x_l, img, audio)
+        logits, z = self._fuse_and_head(outs, [])
+        return (logits, z) if output_gate else logits
+
+
+class MultiprojectionMMTransformerGMUClf(_BPMulTBase):
+    """4-modal BPMulT (text, video, audio, poster).  forward(txt, mask, segment, img, audio, poster, output_gate=False)."""
+    four_modal = True
+
+    def __init__(self, args):
+        super().__init__()
+        self.orig_d_p = args.orig_d_p
+        self._init_common(args)
+        d = self.d
+        self.audio_enc = AudioEncoder(args)
+        self.proj_poster = nn.Linear(self.orig_d_p, d, bias=False)
+        self.gmu = TextShiftingLayer([d, d, d, d], d)
+        self.num_vectors_l = getattr(args, "num_vectors_l", 512)
+        self.num_vectors_a = getattr(args, "num_vectors_a", 200)
+        self.num_vectors_v = getattr(args, "num_vectors_v", 200)
+        self._init_time_maps()
+
+    def forward(self, txt, mask, segment, img, audio, poster, output_gate=False):
+        x_l = self.enc(txt, mask, segment)
+        x_a = self.audio_enc(audio).transpose(1, 2)            # [B,96,A] -> [B,A,96]
+        outs = self._trunk(x_l, img, x_a)
+        logits, z = self._fuse_and_head(outs, [self.proj_poster(poster)])
+        return (logits, z) if output_gate else logits

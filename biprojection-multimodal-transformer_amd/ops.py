@@ -32,15 +32,15 @@ def _stream() -> int:
 
 
 def _p(t) -> Optional[int]:
-    if t is None:
-        return None
+    if t is None or isinstance(t, int):     # raw device address (e.g. an offset into a flat buffer)
+        return t
     if not t.is_cuda:
         raise ValueError("expected a CUDA (HIP) tensor: the BPMulT hot path has no CPU fallback")
     return t.data_ptr()
 
 
 def _f32(t, what):
-    if t is not None and t.dtype != torch.float32:
+    if t is not None and not isinstance(t, int) and t.dtype != torch.float32:
         raise ValueError(f"{what}: expected float32, got {t.dtype}")
     return _p(t)
 
@@ -190,12 +190,12 @@ def ln_bwd(probs, d) -> None:
         _lib.check(_lib.lib().bpm_ln_bwd(sub, k, d, _stream()), "bpm_ln_bwd")
 
 
-def cast_problem(a, lda, R, Cn, *, a_is_ct=False, b=None, ldb=0, dst_ct=None, ldd=0, dst_f32=None, ldf=0, colsum=None,
+def cast_problem(a, lda, R, Cn, *, a_is_ct=False, b=None, ldb=0, dst_ct=None, ldd=0, ct_cols=0, dst_f32=None, ldf=0, colsum=None,
                  drop_p=0.0, drop_site=0) -> CastProblem:
     p = CastProblem()
     p.a, p.lda, p.a_is_ct = _p(a), lda, int(a_is_ct)
     p.b, p.ldb = _f32(b, "cast.b"), ldb
-    p.dst_ct, p.ldd, p.dst_f32, p.ldf = _p(dst_ct), ldd, _f32(dst_f32, "cast.dst_f32"), ldf
+    p.dst_ct, p.ldd, p.ct_cols, p.dst_f32, p.ldf = _p(dst_ct), ldd, ct_cols, _f32(dst_f32, "cast.dst_f32"), ldf
     p.colsum = colsum if isinstance(colsum, int) else _f32(colsum, "cast.colsum")
     p.R, p.C, p.drop_p, p.drop_site = R, Cn, drop_p, drop_site
     return p

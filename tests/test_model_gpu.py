@@ -1,0 +1,118 @@
+"""Whole-model parity on the MI355X against golden vectors produced by the
+reference models (f7: mmtrvat toy, f8: mmtrvapt toy, f9: BASELINE configs[0]
+shape d=300 / 12 heads / 8 layers at B=2).  Inputs and weights are regenerated
+from names (tests/golden/detgen.py); the fixtures hold reference outputs only.
+
+Tolerances: f32 mode -- logits/gates 1e-4 abs on O(1) values (north-star bar is
+1e-3 relative), gradients 2e-3 relative to the tensor's max; bf16 mode --
+stated tolerance 5e-2 relative L2."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from detgen import det, det_param  # noqa: E402
+
+import bpmult_amd  # noqa: E402
+from bpmult_amd.models import get_model  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+T = torch.from_numpy
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def args_for(model, **kw):
+    a = dict(model=model, orig_d_l=768, orig_d_v=35, orig_d_a=74, orig_d_p=4096, hidden_sz=300, vonly=True, lonly=True,
+             aonly=True, num_heads=12, layers=8, attn_dropout=0., attn_dropout_v=0., attn_dropout_a=0., relu_dropout=0.,
+             res_dropout=0., out_dropout=0., embed_dropout=0., attn_mask=True, hybrid=False, n_classes=6,
+             bert_model="unused", text_features=True)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def err(a, b):
+    a = a.detach().float().cpu().numpy()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.isfinite(a).all()
+    return float(np.abs(a - b).max()), max(float(np.abs(b).max()), 1e-6), \
+        float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-12))
+
+
+def check(a, b, prec, what, f32_rel=2e-3, f32_abs=None):
+    e, scale, rel = err(a, b)
+    if prec == "f32":
+        lim = f32_abs if f32_abs is not None else f32_rel * max(scale, 1e-3)
+        assert e <= lim, f"{what}: max err {e:.3e} > {lim:.3e} (scale {scale:.3g})"
+    else:
+        assert rel <= 5e-2, f"{what}: rel-L2 {rel:.3e} (max err {e:.3e}, scale {scale:.3g})"
+
+
+def run_model(g, model, pfx, inputs, call, prec):
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(T(det_param(pfx + k, p.shape)))
+    model.precision = prec
+    model = model.cuda().train()
+    dev = {k: v.cuda().requires_grad_(True) for k, v in inputs.items()}
+    logits, z = call(model, dev)
+    tgt = (T(det(pfx + "tgt", tuple(logits.shape))) > 0).float().cuda()
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, tgt)
+    loss.backward()
+    check(logits, g["logits"], prec, "logits", f32_abs=1e-4 * max(1.0, float(np.abs(g["logits"]).max())))
+    check(z, g["z"], prec, "z", f32_abs=1e-4)
+    check(loss, g["loss"], prec, "loss", f32_abs=1e-4)
+    nograd = set(g["nograd"].tolist())
+    worst = (0.0, "")
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        gn = g["gn." + k]
+        n = p.grad.double().norm().item()
+        rel = abs(n - gn[0]) / max(gn[0], 1e-9)
+        worst = max(worst, (rel, k))
+        assert rel <= (5e-3 if prec == "f32" else 8e-2), f"grad norm of {k}: {n:.6e} vs reference {gn[0]:.6e}"
+        if "g." + k in g:
+            check(p.grad, g["g." + k], prec, "grad " + k)
+    for k, t in dev.items():
+        if "gin." + k in g:
+            check(t.grad, g["gin." + k], prec, "gin." + k)
+    return worst
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_f7_mmtrvat(prec):
+    g = load("f7_mmtrvat")
+    model = get_model(args_for("mmtrvat", hidden_sz=24, num_heads=4, layers=2, orig_d_l=32))
+    assert sorted(k for k, _ in model.named_parameters()) == sorted(g["param_names"].tolist())
+    inputs = {"xl": T(det("f7.xl", (2, 50, 32))), "img": T(det("f7.img", (2, 500, 35))), "aud": T(det("f7.aud", (2, 375, 74)))}
+    run_model(g, model, "f7.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_f8_mmtrvapt(prec):
+    g = load("f8_mmtrvapt")
+    model = get_model(args_for("mmtrvapt", hidden_sz=24, num_heads=4, layers=2, orig_d_l=32, orig_d_v=40, orig_d_a=96,
+                               orig_d_p=64, n_classes=13))
+    assert sorted(k for k, _ in model.named_parameters()) == sorted(g["param_names"].tolist())
+    inputs = {"xl": T(det("f8.xl", (2, 60, 32))), "img": T(det("f8.img", (2, 150, 40))),
+              "aud": T(det("f8.aud", (2, 96, 1000))), "post": T(det("f8.post", (2, 64)))}
+    run_model(g, model, "f8.", inputs,
+              lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], d["post"], output_gate=True), prec)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_f9_cfg1_shape(prec):
+    """d=300, 12 heads (head_dim 25), 8 layers, lengths padded to 512, B=2."""
+    g = load("f9_cfg1")
+    model = get_model(args_for("mmtrvat"))
+    inputs = {"xl": T(det("f9.xl", (2, 20, 768))), "img": T(det("f9.img", (2, 500, 35))), "aud": T(det("f9.aud", (2, 400, 74)))}
+    run_model(g, model, "f9.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec)
