@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""BPMulT hot-path benchmark on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one training pass of the hot path over one synthetic batch that is
+already resident in HBM: zero-grad, forward, BCE-with-logits loss, backward and,
+for N > 1, the RCCL all-reduce of the gradients (the optimizer
+step is reported separately as `optimizer_ms`, it is not part of the metric).
+Default workload = BASELINE.json configs[1]: IEMOCAP-shape 3-modal BPMulT
+(`mmtrvat`, hidden 300, 12 heads, 8 layers, L/V/A = 20/500/400 zero-padded to
+512, per-GPU batch 8, README dropout rates), bf16 MFMA operands.  Weak scaling:
+every rank processes its own batch of 8.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: the kernel kind with
+the largest share of the warm-up is bracketed by HIP events on its launch stream
+during the timed steps (bpm_prof_*), achieved = algorithmic FLOPs / summed
+launch time.  `cpu_baseline` times the CPU oracle (oracle/bpmult_cpu.py, a port
+of the reference arithmetic) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (model, hidden, heads, layers, classes, orig dims l/v/a/p, raw lengths L/V/A, num_vectors l/a/v)
+    "cfg1": dict(model="mmtrvat", hidden_sz=300, num_heads=12, layers=8, n_classes=6, orig_d_l=768, orig_d_v=35, orig_d_a=74,
+                 orig_d_p=4096, L=20, V=500, A=400, nv=(512, 512, 512), batch=8,
+                 desc="IEMOCAP-shape synthetic 3-modal mmtrvat d=300 H=12 layers=8 L/V/A=20/500/400->512"),
+    "cfg3": dict(model="mmtrvapt", hidden_sz=768, num_heads=6, layers=5, n_classes=13, orig_d_l=768, orig_d_v=4096, orig_d_a=96,
+                 orig_d_p=4096, L=512, V=200, A=1000, nv=(512, 200, 200), batch=8,
+                 desc="Moviescope-shape synthetic 4-modal mmtrvapt d=768 H=6 layers=5 L=512 V=A=200"),
+    "k768": dict(model="mmtrvat", hidden_sz=768, num_heads=6, layers=5, n_classes=6, orig_d_l=768, orig_d_v=35, orig_d_a=74,
+                 orig_d_p=4096, L=50, V=50, A=50, nv=(50, 50, 50), batch=64,
+                 desc="kernel point: 3-modal d=768 H=6 layers=5 seq_len=50"),
+}
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def model_args(c, precision, dropout=True):
+    p = (lambda v: v) if dropout else (lambda v: 0.0)
+    return SimpleNamespace(model=c["model"], hidden_sz=c["hidden_sz"], num_heads=c["num_heads"], layers=c["layers"],
+                           n_classes=c["n_classes"], orig_d_l=c["orig_d_l"], orig_d_v=c["orig_d_v"], orig_d_a=c["orig_d_a"],
+                           orig_d_p=c["orig_d_p"], vonly=True, lonly=True, aonly=True, attn_dropout=p(0.1), attn_dropout_v=0.0,
+                           attn_dropout_a=0.0, relu_dropout=p(0.1), res_dropout=p(0.1), out_dropout=0.0, embed_dropout=p(0.25),
+                           attn_mask=True, hybrid=False, bert_model="unused", text_features=True, precision=precision,
+                           num_vectors_l=c["nv"][0], num_vectors_a=c["nv"][1], num_vectors_v=c["nv"][2])
+
+
+def synth_batch(c, B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    b = dict(xl=r(B, c["L"], c["orig_d_l"]), img=r(B, c["V"], c["orig_d_v"]),
+             tgt=(torch.rand(B, c["n_classes"], generator=g) > 0.5).float())
+    if c["model"] == "mmtrvapt":
+        b["aud"] = r(B, 96, c["A"])
+        b["post"] = r(B, c["orig_d_p"])
+    else:
+        b["aud"] = r(B, c["A"], c["orig_d_a"])
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def run_model(model, b):
+    if "post" in b:
+        return model(b["xl"], None, None, b["img"], b["aud"], b["post"])
+    return model(b["xl"], None, None, b["img"], b["aud"])
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota, capped at 16 (the GPU box's share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(c, sample_B, steps):
+    """The CPU oracle (port of the reference arithmetic) on this box's host cores: fwd + bwd, train mode."""
+    from oracle import bpmult_cpu as O
+    torch.manual_seed(1234)
+    four = c["model"] == "mmtrvapt"
+    m = O.ModelCfg(c["hidden_sz"], c["num_heads"], c["layers"], c["n_classes"], orig_d_l=c["orig_d_l"], orig_d_v=c["orig_d_v"],
+                   orig_d_a=c["orig_d_a"], orig_d_p=c["orig_d_p"], attn_dropout=0.1, relu_dropout=0.1, res_dropout=0.1,
+                   embed_dropout=0.25, num_vectors_l=c["nv"][0], num_vectors_a=c["nv"][1], num_vectors_v=c["nv"][2])
+    sd = {k: (torch.randn(s) * 0.05).requires_grad_(True) for k, s in O.model_param_shapes(m, four).items()}
+    b = synth_batch(c, sample_B, 1234, "cpu")
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: {cores} threads, batch {sample_B}, {steps} timed step(s) ...", file=sys.stderr, flush=True)
+
+    def step():
+        for p in sd.values():
+            p.grad = None
+        if four:
+            logits, _ = O.bpmult4_forward(sd, m, b["xl"], b["img"], O.audio_encoder(sd, b["aud"]), b["post"], training=True)
+        else:
+            logits, _ = O.bpmult3_forward(sd, m, b["xl"], b["img"], b["aud"], training=True)
+        torch.nn.functional.binary_cross_entropy_with_logits(logits, b["tgt"]).backward()
+
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step()
+        print(f"[bench] cpu_baseline step {i + 1}/{steps}: {time.perf_counter() - t0:.1f} s elapsed", file=sys.stderr, flush=True)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=round(sample_B / dt, 4), unit="samples/s", cores=cores, kind="port",
+                sample=f"{steps} fwd+bwd step(s) of the same model at batch {sample_B} (fp32, train-mode dropout), "
+                       f"{dt:.2f} s/step, torch {torch.__version__} CPU ops")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg1", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import bpmult_amd
+    from bpmult_amd import _lib
+    from bpmult_amd.distributed import GradSync
+    from bpmult_amd.models import get_model
+
+    c = CONFIGS[a.config]
+    B = a.batch or c["batch"]
+    torch.manual_seed(1234 + rank)
+    model = get_model(model_args(c, a.precision)).to(dev).train()
+    if world > 1:                                     # same replica everywhere
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    sync = GradSync(model)
+    batch = synth_batch(c, B, 1234 + rank, dev)
+    crit = torch.nn.BCEWithLogitsLoss()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = crit(run_model(model, batch), batch["tgt"])
+        loss.backward()
+        sync.finish()
+        return loss
+
+    L = _lib.lib()
+    kinds = _lib.PROF_KINDS
+    L.bpm_prof_enable(sum(1 << k for k in kinds.values()))
+    for _ in range(max(a.warmup, 1)):
+        loss = step()
+    torch.cuda.synchronize()
+    tot = {}
+    for name, k in kinds.items():
+        ms, work, n = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(L.bpm_prof_collect(k, C.byref(ms), C.byref(work), C.byref(n)), "bpm_prof_collect")
+        tot[name] = (ms.value, work.value, n.value)
+    dom = max(tot, key=lambda k: tot[k][0])
+    L.bpm_prof_enable(1 << kinds[dom])
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms, work, n = C.c_double(), C.c_double(), C.c_int()
+    _lib.check(L.bpm_prof_collect(kinds[dom], C.byref(ms), C.byref(work), C.byref(n)), "bpm_prof_collect")
+    L.bpm_prof_enable(0)
+
+    # optimizer step, reported separately (not part of the fwd+bwd metric)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        opt.step()
+    torch.cuda.synchronize()
+    opt_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    if rank == 0:
+        ach = work.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        out = {
+            "metric": "training samples/sec (fwd+bwd) BPMulT",
+            "value": round(world * B * a.steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": c["desc"], "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "dropout": "README rates (attn .1/0/0, relu .1, res .1, embed .25)",
+                       "loss": float(loss.detach()), "optimizer_ms": round(opt_ms, 3),
+                       "kernel_time_share_warmup_ms": {k: round(v[0], 2) for k, v in tot.items()}},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3,
+                         "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
+                         "traffic": None, "launches": n.value, "avg_launch_ms": round(ms.value / max(n.value, 1), 4),
+                         "flops_per_launch": work.value / max(n.value, 1)},
+        }
+        print("[bench] gpu part done: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline")}), file=sys.stderr, flush=True)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c, a.cpu_batch, a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

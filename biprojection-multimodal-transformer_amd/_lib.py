@@ -8,11 +8,19 @@ import ctypes as C
 import os
 import subprocess
 
+# torch must be imported BEFORE the library is dlopen'ed: libbpmult_hip.so then binds to the
+# HIP runtime torch has already loaded (one runtime, one device context per process).  Loaded
+# the other way round, the process ends up with two HIP runtimes and launches fail with
+# hipErrorNoDevice.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libbpmult_hip.so")
-SOURCES = ("gemm.hip", "attention.hip", "rowops.hip")
+SOURCES = ("gemm.hip", "attention.hip", "rowops.hip", "prof.hip")
+HEADERS = ("bpm_common.h", "bpm_prof.h")
 ARCH = "gfx950"
+PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5}
 
 BPM_F32, BPM_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
@@ -25,7 +33,7 @@ MAX_GROUP = 18
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into one shared library (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "bpm_common.h"), os.path.join(_HERE, "..", "include", "bpmult_hip.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(_HERE, "..", "include", "bpmult_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -120,6 +128,8 @@ SIGNATURES = {
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
+    "bpm_prof_enable": [C.c_uint],
+    "bpm_prof_collect": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)],
 }
 
 _lib = None

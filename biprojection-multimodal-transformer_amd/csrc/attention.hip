@@ -25,6 +25,7 @@
 //                  dV^T += dO^T Pd        dK^T += Qs^T dS
 // One wave owns 16 queries (or 16 keys); a 256-thread workgroup owns 64.
 #include "bpm_common.h"
+#include "bpm_prof.h"
 #include "../../include/bpmult_hip.h"
 
 namespace {
@@ -423,6 +424,21 @@ int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S,
     return 0;
 }
 
+// sum over problems of B*H*dh * (number of visible (query, key) pairs): the useful
+// multiply-adds of ONE attention product (P(T,S) = sum_i min(S, i + mask_off))
+double useful_pair_flops(const bpm_attn_problem* probs, int nprob) {
+    double tot = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const bpm_attn_problem& q = probs[i];
+        double pairs = 0;
+        if (q.mask_off <= 0) pairs = (double)q.T * q.S;
+        else
+            for (int t = 0; t < q.T; ++t) pairs += (double)((long)t + q.mask_off < (long)q.S ? t + q.mask_off : q.S);
+        tot += pairs * q.dh * q.B * q.H;
+    }
+    return tot;
+}
+
 template <typename CT>
 int dispatch(int which, int dhp, const AGroup& g, int total, hipStream_t s) {
     dim3 grid(total), block(NTHREADS);
@@ -453,6 +469,7 @@ extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob,
     for (int i = 0; i < nprob; ++i)
         if (!probs[i].Q || !probs[i].K || !probs[i].V || !probs[i].O || !probs[i].lse) return BPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    BpmProfScope prof(BPM_K_ATTN_FWD, s, 4.0 * useful_pair_flops(probs, nprob));
     return dtype == BPM_BF16 ? dispatch<bf16_t>(0, probs[0].dhp, g, total, s) : dispatch<float>(0, probs[0].dhp, g, total, s);
 }
 
@@ -467,9 +484,15 @@ extern "C" int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs, int nprob,
         if (!q.Q || !q.K || !q.V || !q.O || !q.lse || !q.dO || !q.delta || !q.dQ || !q.dK || !q.dV) return BPM_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    rc = dtype == BPM_BF16 ? dispatch<bf16_t>(1, probs[0].dhp, g, total, s) : dispatch<float>(1, probs[0].dhp, g, total, s);
+    // algorithmic backward = dP, dQ (here) + dV, dK (next kernel): 4 * pairs * dh each; recomputing S is overhead
+    const double w = 4.0 * useful_pair_flops(probs, nprob);
+    {
+        BpmProfScope prof(BPM_K_ATTN_BWD_DQ, s, w);
+        rc = dtype == BPM_BF16 ? dispatch<bf16_t>(1, probs[0].dhp, g, total, s) : dispatch<float>(1, probs[0].dhp, g, total, s);
+    }
     if (rc) return rc;
     rc = fill(g, probs, nprob, 1, seed, &total);
     if (rc) return rc;
+    BpmProfScope prof(BPM_K_ATTN_BWD_DKV, s, w);
     return dtype == BPM_BF16 ? dispatch<bf16_t>(2, probs[0].dhp, g, total, s) : dispatch<float>(2, probs[0].dhp, g, total, s);
 }

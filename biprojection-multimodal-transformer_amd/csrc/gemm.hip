@@ -28,6 +28,7 @@
 // row-major (pad columns zeroed) or CT head-major [B,H,T,dhp] (attention
 // operand layout).
 #include "bpm_common.h"
+#include "bpm_prof.h"
 #include "../../include/bpmult_hip.h"
 
 namespace {
@@ -352,5 +353,8 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     }
     g.total_tiles = tile;
     hipStream_t s = (hipStream_t)stream;
+    double flops = 0;
+    for (int i = 0; i < nprob; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * probs[i].K;
+    BpmProfScope prof(BPM_K_GEMM_NT + variant, s, flops);
     return dtype == BPM_BF16 ? launch<bf16_t>(variant, g, s) : launch<float>(variant, g, s);
 }

@@ -365,12 +365,15 @@ class _Trunk:
                 else:
                     d1[name] = gsum.view(shp)
         self._time_backward()
+        self._ready("fuse")
         for (tgt, name), t in self.tmap.items():
             d1[name] = t["dh"]
         dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2])
+        self._ready("level2")
         for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
             d1[src] = d1[src] + gk + gv
         dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1])
+        self._ready("level1")
         acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
             acc[q].append(gq)
@@ -380,8 +383,16 @@ class _Trunk:
         for k, terms in acc.items():
             torch.sum(torch.stack(terms), dim=0, out=self.dpx[k])
         res = self.conv_backward(seed, need_dx)
+        self._ready("proj")
         st.end_backward()
         return res
+
+    def _ready(self, section: str) -> None:
+        hook = getattr(self.m, "_grad_ready_hook", None)
+        if hook is not None:
+            lo, hi = self.st.sections[section]
+            if hi > lo:
+                hook(self.st.gflat, lo, hi)
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -458,9 +469,26 @@ class _BPMulTBase(nn.Module):
 
     def _ensure_store(self) -> ParamStore:
         if self._store is None or not self._store.still_flat():
-            named = [(n, p) for n, p in self.named_parameters() if not n.startswith(self.TAIL)]
+            allp = {n: p for n, p in self.named_parameters() if not n.startswith(self.TAIL)}
+            # flat layout in reverse execution order, so a finished section of the gradient buffer
+            # can be all-reduced while backward continues (distributed.GradSync)
+            secs = [("fuse", lambda n: n.startswith(("gmu_", "transfm_"))),
+                    ("level2", lambda n: n.split(".")[0] in LEVEL2),
+                    ("level1", lambda n: n.split(".")[0] in LEVEL1),
+                    ("proj", lambda n: n.startswith("proj_"))]
+            named, bounds = [], []
+            for sname, pred in secs:
+                part = [(n, p) for n, p in allp.items() if pred(n)]
+                bounds.append((sname, len(named), len(named) + len(part)))
+                named += part
+            assert len(named) == len(allp), "every trunk parameter belongs to exactly one section"
             dt = config.dtype_code(self.precision or config.precision())
             st = ParamStore(named, dt)
+            st.sections = {}
+            for sname, a, b in bounds:
+                lo = st.off[named[a][0]] if b > a else 0
+                hi = (st.off[named[b][0]] if b < len(named) else st.total) if b > a else 0
+                st.sections[sname] = (lo, hi)
             d = self.d
             for n in ENC_ORDER:
                 register_encoder_shadows(st, n + ".", d, self.layers)

@@ -199,6 +199,20 @@ typedef struct bpm_gmu_problem {
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Launch profiler (measurement aid for bench.py; no reference counterpart).
+ * While bit `kind` of the mask is set, every launch of that kernel kind is
+ * bracketed by two HIP events ON ITS LAUNCH STREAM and its algorithmic work is
+ * tallied (GEMM: 2*M*N*K; attention: 2 FLOPs per visible (query,key) pair per
+ * head-dim element per algorithmic product, recomputation not counted).
+ * bpm_prof_collect waits for the recorded events, returns the summed
+ * per-launch durations (ms), work and launch count of one kind, and clears them.
+ * ---------------------------------------------------------------------- */
+enum { BPM_PROF_GEMM_NT = 0, BPM_PROF_GEMM_NN = 1, BPM_PROF_GEMM_TN = 2, BPM_PROF_ATTN_FWD = 3,
+       BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5 };
+int bpm_prof_enable(unsigned kind_mask);
+int bpm_prof_collect(int kind, double* total_ms, double* total_work, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

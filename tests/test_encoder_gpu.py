@@ -44,7 +44,7 @@ def close(a, b, tol, what):
         assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e}"
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 1e-1)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 2e-1)])
 @pytest.mark.parametrize("tag,bi,Tn,S,mask", [("x", False, 7, 5, True), ("xn", False, 6, 6, False), ("x25", False, 8, 11, True),
                                              ("b", True, 5, 8, True)])
 def test_f5_encoder(prec, tol, tag, bi, Tn, S, mask):

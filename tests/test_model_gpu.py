@@ -45,13 +45,16 @@ def err(a, b):
         float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-12))
 
 
-def check(a, b, prec, what, f32_rel=2e-3, f32_abs=None):
+BF16_FWD, BF16_GRAD = 5e-2, 2e-1     # stated bf16-mode tolerances (relative L2): outputs / gradients
+
+
+def check(a, b, prec, what, f32_rel=2e-3, f32_abs=None, bf16_rel=BF16_FWD):
     e, scale, rel = err(a, b)
     if prec == "f32":
         lim = f32_abs if f32_abs is not None else f32_rel * max(scale, 1e-3)
         assert e <= lim, f"{what}: max err {e:.3e} > {lim:.3e} (scale {scale:.3g})"
     else:
-        assert rel <= 5e-2, f"{what}: rel-L2 {rel:.3e} (max err {e:.3e}, scale {scale:.3g})"
+        assert rel <= bf16_rel, f"{what}: rel-L2 {rel:.3e} (max err {e:.3e}, scale {scale:.3g})"
 
 
 def run_model(g, model, pfx, inputs, call, prec):
@@ -79,12 +82,12 @@ def run_model(g, model, pfx, inputs, call, prec):
         n = p.grad.double().norm().item()
         rel = abs(n - gn[0]) / max(gn[0], 1e-9)
         worst = max(worst, (rel, k))
-        assert rel <= (5e-3 if prec == "f32" else 8e-2), f"grad norm of {k}: {n:.6e} vs reference {gn[0]:.6e}"
+        assert rel <= (5e-3 if prec == "f32" else 1e-1), f"grad norm of {k}: {n:.6e} vs reference {gn[0]:.6e}"
         if "g." + k in g:
-            check(p.grad, g["g." + k], prec, "grad " + k)
+            check(p.grad, g["g." + k], prec, "grad " + k, bf16_rel=BF16_GRAD)
     for k, t in dev.items():
         if "gin." + k in g:
-            check(t.grad, g["gin." + k], prec, "gin." + k)
+            check(t.grad, g["gin." + k], prec, "gin." + k, bf16_rel=BF16_GRAD)
     return worst
 
 
