@@ -16,7 +16,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libbpmult_hip.so")
+LIB_PATH = os.environ.get("BPMULT_LIB", os.path.join(_HERE, "libbpmult_hip.so"))   # override: kernel-variant experiments
 SOURCES = ("gemm.hip", "attention.hip", "rowops.hip", "prof.hip")
 HEADERS = ("bpm_common.h", "bpm_prof.h")
 ARCH = "gfx950"

@@ -13,9 +13,9 @@
 // chunks with chunk-granular guards only.
 //
 // Tile: 128(M) x 64(N) per 256-thread workgroup, 4 waves as 2x2, each wave
-// 64x32 = 4x2 MFMA tiles.  k is consumed 128 bytes (2 k-steps) per stage
+// 64x32 = 4x2 MFMA tiles.  k is consumed one or two 64-byte k-steps per stage
 // through double-buffered, register-staged LDS images:
-//   k-contiguous operand  -> image [rows][128 B + 16 B pad]  read with ds_read_b128
+//   k-contiguous operand  -> image [rows][stage bytes + 16 B pad]  read with ds_read_b128
 //   k-strided   operand  -> image [k][rows*sz + pad]        read transposed
 //                            (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32)
 // The MFMA is issued "swapped" (Y rows as the A operand, X rows as the B
@@ -33,13 +33,21 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
-constexpr int KSTEPS = 2;                 // 64-byte k-steps per stage
-constexpr int BKB = KSTEPS * 64;          // bytes of k per stage and row
+#ifndef BPM_GEMM_BM
+#define BPM_GEMM_BM 128
+#endif
+#ifndef BPM_GEMM_BN
+#define BPM_GEMM_BN 64
+#endif
+constexpr int BM = BPM_GEMM_BM, BN = BPM_GEMM_BN, WM = 2, WN = 2;
 constexpr int NTHREADS = 256;
 constexpr int TM = BM / WM / 16;          // 4 MFMA tiles along m per wave
 constexpr int TN = BN / WN / 16;          // 2 along n
-constexpr int ROW_STRIDE = BKB + 16;      // k-contiguous image row stride (bytes)
+// 64-byte k-steps per LDS stage.  Measured on MI355X at the model's shapes (tools/bench_kernels.py):
+// the forward / dgrad GEMMs have short k loops (K = 300) and are latency bound, so the smaller stage
+// (27 KB of LDS, 5 workgroups per CU in flight) wins by 25-50 %; the weight-gradient GEMM (K = T*B rows)
+// prefers the longer stage.
+constexpr int KS_FWD = 1, KS_WGRAD = 2;
 
 struct Prob {
     const char* X; const char* Y; char* C;
@@ -63,8 +71,10 @@ struct Group {
     Prob p[BPM_MAX_GROUP];
 };
 
-template <typename CT, bool KCONTIG, int ROWS>
+template <typename CT, bool KCONTIG, int ROWS, int KSTEPS>
 struct Side {
+    static constexpr int BKB = KSTEPS * 64;          // bytes of k per stage and row
+    static constexpr int ROW_STRIDE = BKB + 16;      // k-contiguous image row stride (bytes)
     static constexpr int SZ = sizeof(CT);
     static constexpr int EPC = Tr<CT>::EPC;
     static constexpr int BK = KSTEPS * Tr<CT>::KSTEP;                    // elements of k per stage
@@ -140,10 +150,10 @@ BPM_DEV void store_ct4(char* C, size_t off_elems, const float (&v)[4], int nvali
     }
 }
 
-template <typename CT, bool XK, bool YK>
+template <typename CT, bool XK, bool YK, int KSTEPS>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
-    typedef Side<CT, XK, BM> SX;
-    typedef Side<CT, YK, BN> SY;
+    typedef Side<CT, XK, BM, KSTEPS> SX;
+    typedef Side<CT, YK, BN, KSTEPS> SY;
     constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -235,37 +245,64 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
         for (int a = 0; a < TN; ++a) {
             const int nb = n0 + wn * (BN / WN) + 16 * a + 4 * g;
             float v[4];
+            const bool full = nb + 3 < P.N;
+            // side operands: one 16-byte (f32) / 8-byte (bf16) load per lane where the 4 columns are in range and aligned
+            float bn[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {1.f, 1.f, 1.f, 1.f};
+            if (lead && P.bias_n) {
+                const float* bp = P.bias_n + nb;
+                if (full && (((uintptr_t)bp & 15) == 0)) { const f32x4 t = *(const f32x4*)bp; bn[0] = t[0]; bn[1] = t[1]; bn[2] = t[2]; bn[3] = t[3]; }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (nb + q < P.N) bn[q] = bp[q];
+                }
+            }
+            if (lead && P.resid) {
+                const float* rp = P.resid + (size_t)m * P.ldr + nb;
+                if (full && (((uintptr_t)rp & 15) == 0)) { const f32x4 t = *(const f32x4*)rp; rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (nb + q < P.N) rs[q] = rp[q];
+                }
+            }
+            if (P.gate) {
+                const CT* gp = (const CT*)P.gate + (size_t)m * P.ldg + nb;
+                if (nb + 3 < P.ldg) {          // gate rows are padded CT rows: an aligned 4-element read is always in bounds
+                    if constexpr (sizeof(CT) == 4) { const f32x4 t = *(const f32x4*)gp; gt[0] = t[0]; gt[1] = t[1]; gt[2] = t[2]; gt[3] = t[3]; }
+                    else { const bf16x4 t = *(const bf16x4*)gp; gt[0] = (float)t[0]; gt[1] = (float)t[1]; gt[2] = (float)t[2]; gt[3] = (float)t[3]; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (nb + q < P.N) gt[q] = Tr<CT>::to_f(gp[q]);
+                }
+            }
+            const float bm = (lead && P.bias_m) ? P.bias_m[m] : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = nb + q;
-                float x = acc[a][b][q];
+                float x = 0.f;
                 if (n < P.N) {
-                    if (lead) {
-                        if (P.bias_n) x += P.bias_n[n];
-                        if (P.bias_m) x += P.bias_m[m];
-                    }
-                    x *= P.alpha;
+                    x = (acc[a][b][q] + bn[q] + bm) * P.alpha;
                     if (relu) x = fmaxf(x, 0.f);
-                    if (P.gate) {
-                        const float gv = Tr<CT>::to_f(((const CT*)P.gate)[(size_t)m * P.ldg + n]);
-                        x = gv > 0.f ? x * P.gate_scale : 0.f;
-                    }
+                    if (P.gate) x = gt[q] > 0.f ? x * P.gate_scale : 0.f;
                     x *= bpm_drop_mult(P.drop, (uint32_t)m * (uint32_t)P.N + (uint32_t)n);
                     csum[a][q] += x;
-                    if (P.resid && lead) x += P.resid[(size_t)m * P.ldr + n];
-                } else {
-                    x = 0.f;
+                    x += rs[q];
                 }
                 v[q] = x;
             }
             if (P.out_kind == BPM_OUT_F32) {
                 float* c = (float*)P.C + (size_t)m * P.ldc + nb;
+                if (full && !atomic && (((uintptr_t)c & 15) == 0)) {
+                    f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+                    if (accum) o += *(const f32x4*)c;
+                    *(f32x4*)c = o;
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (nb + q >= P.N) continue;
-                    if (atomic) atomicAdd(c + q, v[q]);
-                    else if (accum) c[q] += v[q];
-                    else c[q] = v[q];
+                    for (int q = 0; q < 4; ++q) {
+                        if (nb + q >= P.N) continue;
+                        if (atomic) atomicAdd(c + q, v[q]);
+                        else if (accum) c[q] += v[q];
+                        else c[q] = v[q];
+                    }
                 }
             } else if (P.out_kind == BPM_OUT_CT) {
                 const int nvalid = min(4, P.ldc - nb);   // pad columns [N, ldc) get zeros
@@ -302,9 +339,9 @@ template <typename CT>
 int launch(int variant, const Group& g, hipStream_t s) {
     dim3 grid(g.total_tiles), block(NTHREADS);
     switch (variant) {
-        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<CT, true, true>), grid, block, 0, s, g); break;
-        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<CT, true, false>), grid, block, 0, s, g); break;
-        case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<CT, false, false>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<CT, true, true, KS_FWD>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<CT, true, false, KS_FWD>), grid, block, 0, s, g); break;
+        case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<CT, false, false, KS_WGRAD>), grid, block, 0, s, g); break;
         default: return BPM_ERR_ARG;
     }
     BPM_CHECK_LAUNCH();

@@ -409,7 +409,7 @@ class EncoderGroupPlan:
         for i in reversed(range(c.layers)):
             cast2, wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], [], []
             cast1, wg_att, dg_out, att, csum, dg_q, dg_kv, lnq, lnkv = [], [], [], [], [], [], [], [], []
-            s_cast0, s_dgout0, s_att0, s_csum0, s_wg0, s_dg0a, s_dg0b, s_ln0 = [], [], [], [], [], [], [], []
+            s_cast0, s_dgout0, s_att0, s_csum0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], [], []
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
                 P = lambda leaf: st.p(self._pn(e, i, leaf))
@@ -425,11 +425,11 @@ class EncoderGroupPlan:
                 cast2.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("fc2.bias"),
                                               drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES2)))
                 wg_ffn.append(ops.gemm_problem(b["dy"], b["h1"][i], GP("fc2.weight"), d, 4 * d, R, ld, ld4, 4 * d,
-                                               flags=F_ATOMIC, splitk=sk(d, 4 * d)))
+                                               flags=F_ACCUM))
                 dg_fc2.append(ops.gemm_problem(b["dy"], st.sptr(w2), b["dh1"], R, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
                                                gate_scale=inv_relu, colsum=GP("fc1.bias"), out_kind=OUT_CT))
                 wg_ffn.append(ops.gemm_problem(b["dh1"], b["xn2"][i], GP("fc1.weight"), 4 * d, d, R, ld4, ld, d,
-                                               flags=F_ATOMIC, splitk=sk(4 * d, d)))
+                                               flags=F_ACCUM))
                 dg_fc1.append(ops.gemm_problem(b["dh1"], st.sptr(w1), b["dxn"], R, d, 4 * d, ld4, ld, d))
                 lnf.append(ops.ln_problem(b["xmid"][i], P(f"layer_norms.{lnF}.weight"), None, stF[0], stF[1], R, dy=b["dxn"], ldy=d,
                                           add=dx, dx=dx, dgamma=GP(f"layer_norms.{lnF}.weight"), dbeta=GP(f"layer_norms.{lnF}.bias")))
@@ -437,7 +437,7 @@ class EncoderGroupPlan:
                 cast1.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("self_attn.out_proj.bias"),
                                               drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES1)))
                 wg_att.append(ops.gemm_problem(b["dy"], b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
-                                               flags=F_ATOMIC, splitk=sk(d, d)))
+                                               flags=F_ACCUM))
                 dg_out.append(ops.gemm_problem(b["dy"], st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                heads=(B, H, e.T, dh, dhp)))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
@@ -449,8 +449,7 @@ class EncoderGroupPlan:
                     csum.append(ops.cast_problem(src, ld, rows, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
                 for w, dsrc, act, rows in ((0, b["dq"], q_src, R), (1, b["dk"], b["kn"][i], Rk), (2, b["dv"], b["vn"][i], Rk)):
-                    wg_att.append(ops.gemm_problem(dsrc, act, st.gptr(ipw, w * d * d), d, d, rows, ld, ld, d, flags=F_ATOMIC,
-                                                   splitk=_splitk(3 * 5 * G * 4, rows)))
+                    wg_att.append(ops.gemm_problem(dsrc, act, st.gptr(ipw, w * d * d), d, d, rows, ld, ld, d, flags=F_ACCUM))
                 if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
                     dg_q.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
                 else:
@@ -469,7 +468,7 @@ class EncoderGroupPlan:
                     s_cast0.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("self_attn.out_proj.bias"),
                                                     drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
                     s_wg0.append(ops.gemm_problem(b["dy"], b["aos"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
-                                                  flags=F_ATOMIC, splitk=sk(d, d)))
+                                                  flags=F_ACCUM))
                     s_dgout0.append(ops.gemm_problem(b["dy"], st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                      heads=(B, H, e.T, dh, dhp)))
                     s_att0.append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H, e.T, e.T,
@@ -478,11 +477,12 @@ class EncoderGroupPlan:
                                                    drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
                     for w, src in ((0, b["dq"]), (1, b["dks"]), (2, b["dvs"])):
                         s_csum0.append(ops.cast_problem(src, ld, R, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
-                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, ld, ld, d, flags=F_ATOMIC,
-                                                      splitk=_splitk(3 * 5 * G * 4, R)))
+                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, ld, ld, d, flags=F_ACCUM))
+                    # d(xn) = dq Wq + dk Wk + dv Wv: three launches (plain store, then two +=) -- one owner per
+                    # output tile in each launch, no atomics (per-lane-scattered float atomics run ~17x below store rate)
                     s_dg0a.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
-                    s_dg0b.append(ops.gemm_problem(b["dks"], st.sptr(ipw, d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ATOMIC))
-                    s_dg0b.append(ops.gemm_problem(b["dvs"], st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ATOMIC))
+                    s_dg0b.append(ops.gemm_problem(b["dks"], st.sptr(ipw, d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
+                    s_dg0c.append(ops.gemm_problem(b["dvs"], st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
                     s_ln0.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R,
                                                 dy=b["dxn"], ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"),
                                                 dbeta=GP("layer_norms.0.bias")))
@@ -509,6 +509,7 @@ class EncoderGroupPlan:
                           self._gemm(GEMM_TN, s_wg0),
                           self._gemm(GEMM_NN, s_dg0a),
                           self._gemm(GEMM_NN, s_dg0b),
+                          self._gemm(GEMM_NN, s_dg0c),
                           (ops.ln_bwd, A(LnProblem, s_ln0), d)]
         return steps
 

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import config, ops
-from .._lib import BPM_F32, F_ATOMIC, GEMM_NN, GEMM_NT, GEMM_TN, OUT_F32, CastProblem, GemmProblem, GmuProblem
+from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, OUT_F32, CastProblem, GemmProblem, GmuProblem
 from ..engine import (SITE_TEXT, EncoderDesc, EncoderGroupPlan, GroupCfg, ParamStore, _splitk, register_encoder_shadows)
 from ..ops import pad32
 from .encoder import TransformerEncoder
@@ -218,7 +218,7 @@ class _Trunk:
             kp = pad32(od)
             casts.append(ops.cast_problem(self.dpx[k], d, R, d, dst_ct=c["dy"], ldd=self.ld))
             wg.append(ops.gemm_problem(c["dy"], c["packed"], st.gptr(f"proj_{k}.weight"), d, od, R, self.ld, kp, od,
-                                       flags=F_ATOMIC, splitk=_splitk(6, R)))
+                                       flags=F_ACCUM))
             if need_dx[k]:
                 res[k] = torch.empty_like(c["x"])
                 dg.append(ops.gemm_problem(c["dy"], st.sptr(f"proj_{k}.weight"), c["dpk"], R, od, d, self.ld, kp, od))
@@ -256,9 +256,9 @@ class _Trunk:
         for (tgt, src), t in self.tmap.items():
             casts.append(ops.cast_problem(t["dout"], BD, t["Td"], BD, dst_ct=t["dout_ct"], ldd=t["ldbd"]))
             wg.append(ops.gemm_problem(t["dout_ct"], t["h_ct"], st.gptr(t["lin"] + ".weight"), t["Td"], t["Ts"], BD, t["ldbd"], t["ldbd"],
-                                       t["Ts"], flags=F_ATOMIC, splitk=_splitk(16, BD)))
+                                       t["Ts"], flags=F_ACCUM))
             wg.append(ops.gemm_problem(t["dout_ct"], self.ones_bd, st.gptr(t["lin"] + ".bias"), t["Td"], 1, BD, t["ldbd"], t["ldbd"], 1,
-                                       flags=F_ATOMIC, splitk=_splitk(16, BD)))
+                                       flags=F_ACCUM))
             dg.append(ops.gemm_problem(st.sptr(t["lin"] + ".weight"), t["dout_ct"], t["dh"], t["Ts"], BD, t["Td"], pad32(t["Ts"]),
                                        t["ldbd"], BD))
         ops.rows_cast(self.dtype, casts, 0)
@@ -275,7 +275,7 @@ class _Trunk:
         B, d, ld, st = self.B, self.d, self.ld, self.st
         A = ops.array
         casts, gemms, gates = [], [], []
-        bw_gate, bw_wg, bw_dg = [], [], []
+        bw_gate, bw_wg, bw_dg, bw_dg2 = [], [], [], []
         for tgt in ("l", "a", "v"):
             l2a, l1a, l2b, l1b = FUSE[tgt]
             xa, xb = self._lvl1(tgt, l1a), self._lvl1(tgt, l1b)
@@ -297,18 +297,18 @@ class _Trunk:
                 g["dout"] = torch.zeros(self.N[tgt], B, d, device=st.device)
                 bw_gate.append(ops.gmu_problem(g["a1"], g["a2"], g["ag"], g["x1"], g["x2"], R, dout=g["dout"], da1=g["da1"], da2=g["da2"],
                                                dag=g["dag"], ldg=ld, dx1=g["dx1"], dx2=g["dx2"]))
-                sk = _splitk(24 * 25, R)
-                bw_wg += [ops.gemm_problem(g["da1"], xc1, st.gptr(w1), d, d, R, ld, 2 * ld, d, flags=F_ATOMIC, splitk=sk),
-                          ops.gemm_problem(g["da2"], xc2, st.gptr(w2), d, d, R, ld, 2 * ld, d, flags=F_ATOMIC, splitk=sk),
-                          ops.gemm_problem(g["dag"], xc1, st.gptr(wg_), d, d, R, ld, 2 * ld, 2 * d, flags=F_ATOMIC, splitk=sk),
-                          ops.gemm_problem(g["dag"], xc2, st.gptr(wg_, d), d, d, R, ld, 2 * ld, 2 * d, flags=F_ATOMIC, splitk=sk)]
-                # dx1 / dx2 already hold the direct terms; the linear paths are added atomically
-                bw_dg += [ops.gemm_problem(g["da1"], st.sptr(w1), g["dx1"], R, d, d, ld, ld, d, flags=F_ATOMIC),
-                          ops.gemm_problem(g["dag"], st.sptr(wg_), g["dx1"], R, d, d, ld, 2 * ld, d, flags=F_ATOMIC),
-                          ops.gemm_problem(g["da2"], st.sptr(w2), g["dx2"], R, d, d, ld, ld, d, flags=F_ATOMIC),
-                          ops.gemm_problem(g["dag"], st.sptr(wg_, ld), g["dx2"], R, d, d, ld, 2 * ld, d, flags=F_ATOMIC)]
+                bw_wg += [ops.gemm_problem(g["da1"], xc1, st.gptr(w1), d, d, R, ld, 2 * ld, d, flags=F_ACCUM),
+                          ops.gemm_problem(g["da2"], xc2, st.gptr(w2), d, d, R, ld, 2 * ld, d, flags=F_ACCUM),
+                          ops.gemm_problem(g["dag"], xc1, st.gptr(wg_), d, d, R, ld, 2 * ld, 2 * d, flags=F_ACCUM),
+                          ops.gemm_problem(g["dag"], xc2, st.gptr(wg_, d), d, d, R, ld, 2 * ld, 2 * d, flags=F_ACCUM)]
+                # dx1 / dx2 already hold the direct terms; the two linear paths are added by two launches
+                # (one owner per output tile in each: plain += instead of float atomics)
+                bw_dg += [ops.gemm_problem(g["da1"], st.sptr(w1), g["dx1"], R, d, d, ld, ld, d, flags=F_ACCUM),
+                          ops.gemm_problem(g["da2"], st.sptr(w2), g["dx2"], R, d, d, ld, ld, d, flags=F_ACCUM)]
+                bw_dg2 += [ops.gemm_problem(g["dag"], st.sptr(wg_), g["dx1"], R, d, d, ld, 2 * ld, d, flags=F_ACCUM),
+                           ops.gemm_problem(g["dag"], st.sptr(wg_, ld), g["dx2"], R, d, d, ld, 2 * ld, d, flags=F_ACCUM)]
         self._gmu_fwd = (A(CastProblem, casts), A(GemmProblem, gemms), A(GmuProblem, gates))
-        self._gmu_bwd = (A(GmuProblem, bw_gate), A(GemmProblem, bw_wg), A(GemmProblem, bw_dg))
+        self._gmu_bwd = (A(GmuProblem, bw_gate), A(GemmProblem, bw_wg), A(GemmProblem, bw_dg), A(GemmProblem, bw_dg2))
 
     def gmu_forward(self) -> None:
         casts, gemms, gates = self._gmu_fwd
@@ -317,10 +317,11 @@ class _Trunk:
         ops.gmu2_fwd(gates, self.d)
 
     def gmu_backward(self) -> None:
-        gate, wg, dg = self._gmu_bwd
+        gate, wg, dg, dg2 = self._gmu_bwd
         ops.gmu2_bwd(self.dtype, gate, self.d)
         ops.gemm_grouped(self.dtype, GEMM_TN, wg, 0)
         ops.gemm_grouped(self.dtype, GEMM_NN, dg, 0)
+        ops.gemm_grouped(self.dtype, GEMM_NN, dg2, 0)
 
     # -- whole trunk ------------------------------------------------------------------
     def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> List[torch.Tensor]:
