@@ -141,11 +141,19 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
+    # BENCH_REHEARSAL=1: all ranks share cuda:0 and talk over gloo -- only to exercise the N > 1 code path
+    # (sectioned all-reduce on a side stream, rank-max timing) on a one-GPU box; never a measurement.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import bpmult_amd
     from bpmult_amd import _lib

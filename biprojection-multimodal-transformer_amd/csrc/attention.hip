@@ -24,6 +24,12 @@
 //   dK/dV        : S   = Qs K^T   -> rows = queries, lane = key
 //                  dV^T += dO^T Pd        dK^T += Qs^T dS
 // One wave owns 16 queries (or 16 keys); a 256-thread workgroup owns 64.
+//
+// At head_dim 25 the kernels are VALU-bound (16 exponentials per 8 MFMAs), so
+// the element loops are kept to a handful of instructions: visibility is one
+// compare against a per-lane limit and is skipped altogether on tiles that a
+// wave-uniform test proves fully visible; dropout hashing runs only when
+// enabled; exponentials are raw v_exp_f32.
 #include "bpm_common.h"
 #include "bpm_prof.h"
 #include "../../include/bpmult_hip.h"
@@ -95,6 +101,8 @@ BPM_DEV const AProb& pick(const AGroup& grp, int& bid) {
     return grp.p[pi];
 }
 
+BPM_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32: exp2(-inf) = 0, no denormal fix-up
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -112,7 +120,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
     const int b = bh / P.H, h = bh % P.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int q = qb * 64 + wave * 16 + c;            // this lane's query
+    const int q0 = qb * 64 + wave * 16;               // wave-uniform first query
+    const int q = q0 + c;                             // this lane's query
     const char* Qh = P.Q + (size_t)bh * P.T * C::ROWB;
     const char* Kh = P.K + (size_t)bh * P.S * C::ROWB;
     const char* Vh = P.V + (size_t)bh * P.S * C::ROWB;
@@ -127,8 +136,11 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int q_hi = min(P.T, qb * 64 + 64) - 1;
-    const long jmax = min((long)P.S - 1, (long)q_hi + P.mask_off - 1);
-    const int ntile = (int)(jmax / KT) + 1;
+    const int jend = min(P.S, q_hi + P.mask_off);      // one past the last key any query of this block sees (mask_off < 2^30)
+    const int ntile = (jend + KT - 1) / KT;
+    const int lim = min(P.S, q + P.mask_off);          // this lane sees keys j < lim
+    const int lim_min = min(P.S, q0 + P.mask_off);     // every lane of the wave sees keys j < lim_min
+    const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
 
 #pragma unroll 1
@@ -146,31 +158,37 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
             for (int s = 0; s < C::NKS; ++s) a = Tr<CT>::mma(read_rowfrag<CT>(kimg, C::STRIDE, 16 * n, s, lane), qf[s], a);
             st[n] = a;
         }
-        float mx = -INFINITY;
+        const int jb = kt * KT + 4 * g;                // key of element (n, r) is jb + 16n + r
+        if (kt * KT + KT > lim_min) {                  // wave-uniform: only tiles that touch the mask edge pay for it
+            const int rel = lim - jb;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = kt * KT + 16 * n + 4 * g + r;
-                const bool vis = (j < P.S) && ((long)j - q < (long)P.mask_off);
-                st[n][r] = vis ? st[n][r] : -INFINITY;
-                mx = fmaxf(mx, st[n][r]);
-            }
+                for (int r = 0; r < 4; ++r) st[n][r] = (16 * n + r < rel) ? st[n][r] : -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])), fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])), fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * LOG2E);
+        const float alpha = fast_exp2((m_run - m_new) * LOG2E);
+        const float mneg = -m_new * LOG2E;
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f((st[n][r] - m_new) * LOG2E);
+                const float p = fast_exp2(fmaf(st[n][r], LOG2E, mneg));
                 psum += p;
-                const int j = kt * KT + 16 * n + 4 * g + r;
-                st[n][r] = p * bpm_drop_mult(P.drop, drow + (uint32_t)j);
+                st[n][r] = p;
             }
+        if (dropping) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[n][r] *= bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+        }
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int n = 0; n < C::ND; ++n) o[n] *= alpha;
@@ -216,7 +234,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
     const int b = bh / P.H, h = bh % P.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int q = qb * 64 + wave * 16 + c;
+    const int q0 = qb * 64 + wave * 16;
+    const int q = q0 + c;
     const char* Qh = P.Q + (size_t)bh * P.T * C::ROWB;
     const char* dOh = P.dO + (size_t)bh * P.T * C::ROWB;
     const char* Kh = P.K + (size_t)bh * P.S * C::ROWB;
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
     }
     delta += __shfl_xor(delta, 16);
     delta += __shfl_xor(delta, 32);
-    const float lse = (q < P.T) ? P.lse[(size_t)bh * P.T + q] : 0.f;
+    const float lse2 = (q < P.T) ? -P.lse[(size_t)bh * P.T + q] * LOG2E : 0.f;
     if (q < P.T && g == 0) P.delta[(size_t)bh * P.T + q] = delta;
 
     f32x4 dq[C::ND];
@@ -247,8 +266,11 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
     for (int n = 0; n < C::ND; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int q_hi = min(P.T, qb * 64 + 64) - 1;
-    const long jmax = min((long)P.S - 1, (long)q_hi + P.mask_off - 1);
-    const int ntile = (int)(jmax / KT) + 1;
+    const int jend = min(P.S, q_hi + P.mask_off);
+    const int ntile = (jend + KT - 1) / KT;
+    const int lim = min(P.S, q + P.mask_off);
+    const int lim_min = min(P.S, q0 + P.mask_off);
+    const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
 
 #pragma unroll 1
@@ -257,6 +279,9 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
         load_rows<CT, DHP, KT>(kimg, Kh, kt * KT, P.S, tid);
         load_rows<CT, DHP, KT>(vimg, Vh, kt * KT, P.S, tid);
         __syncthreads();
+        const int jb = kt * KT + 4 * g;
+        const bool edge = kt * KT + KT > lim_min;
+        const int rel = lim - jb;
         f32x4 ds[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -268,11 +293,12 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = kt * KT + 16 * n + 4 * g + r;
-                const bool vis = (j < P.S) && ((long)j - q < (long)P.mask_off);
-                const float p = vis ? exp2f((s_[r] - lse) * LOG2E) : 0.f;
-                const float dm = bpm_drop_mult(P.drop, drow + (uint32_t)j);
-                ds[n][r] = p * (dp[r] * dm - delta);
+                float e = fmaf(s_[r], LOG2E, lse2);
+                if (edge) e = (16 * n + r < rel) ? e : -INFINITY;      // exp2(-inf) = 0: masked before the exponential
+                const float p = fast_exp2(e);
+                float dpv = dp[r];
+                if (dropping) dpv *= bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+                ds[n][r] = p * (dpv - delta);
             }
         }
         // dQ^T += K^T dS^T
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
     __shared__ __attribute__((aligned(16))) char smem[2 * QT * C::STRIDE + 2 * QT * 4];
     char* qimg = smem;
     char* doimg = smem + QT * C::STRIDE;
-    float* s_lse = (float*)(smem + 2 * QT * C::STRIDE);
+    float* s_lse = (float*)(smem + 2 * QT * C::STRIDE);      // -lse * log2(e)
     float* s_del = s_lse + QT;
 
     int bid = blockIdx.x;
@@ -315,7 +341,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
     const int b = bh / P.H, h = bh % P.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int j = kb * 64 + wave * 16 + c;            // this lane's key
+    const int j0 = kb * 64 + wave * 16;                // wave-uniform first key
+    const int j = j0 + c;                              // this lane's key
     const char* Qh = P.Q + (size_t)bh * P.T * C::ROWB;
     const char* dOh = P.dO + (size_t)bh * P.T * C::ROWB;
     const char* Kh = P.K + (size_t)bh * P.S * C::ROWB;
@@ -331,10 +358,13 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
 #pragma unroll
     for (int n = 0; n < C::ND; ++n) { dk[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // first query that can see any key of this block: i > k0 - mask_off
-    const long i_lo = max(0L, (long)kb * 64 - (long)P.mask_off + 1);
-    const int qt_lo = (int)(i_lo / QT);
+    // query i sees key j iff i >= ilo = j - mask_off + 1 (and i < T, j < S)
+    const int ilo = (j < P.S) ? j - P.mask_off + 1 : (1 << 30);
+    const int ilo_max = (j0 + 15 < P.S) ? j0 + 15 - P.mask_off + 1 : (1 << 30);   // wave-uniform: tiles at or above it need no test
+    const int i_first = max(0, kb * 64 - P.mask_off + 1);                            // first query that sees any key of the block
+    const int qt_lo = i_first / QT;
     const int qt_hi = (P.T + QT - 1) / QT;
+    const bool dropping = P.drop.thresh != 0;
 
 #pragma unroll 1
     for (int qt = qt_lo; qt < qt_hi; ++qt) {
@@ -343,10 +373,11 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
         load_rows<CT, DHP, QT>(doimg, dOh, qt * QT, P.T, tid);
         if (tid < QT) {
             const int i = qt * QT + tid;
-            s_lse[tid] = i < P.T ? P.lse[(size_t)bh * P.T + i] : 0.f;
+            s_lse[tid] = i < P.T ? -P.lse[(size_t)bh * P.T + i] * LOG2E : 0.f;
             s_del[tid] = i < P.T ? P.delta[(size_t)bh * P.T + i] : 0.f;
         }
         __syncthreads();
+        const bool edge = (qt * QT < ilo_max) || (qt * QT + QT > P.T);
         f32x4 pd[2], ds[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -356,15 +387,18 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
                 s_ = Tr<CT>::mma(read_rowfrag<CT>(qimg, C::STRIDE, 16 * u, s, lane), kf[s], s_);
                 dp = Tr<CT>::mma(read_rowfrag<CT>(doimg, C::STRIDE, 16 * u, s, lane), vf[s], dp);
             }
+            const f32x4 l4 = *(const f32x4*)(s_lse + 16 * u + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(s_del + 16 * u + 4 * g);
+            const int ib = qt * QT + 16 * u + 4 * g;       // query of element r is ib + r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int il = 16 * u + 4 * g + r;
-                const int i = qt * QT + il;
-                const bool vis = (i < P.T) && (j < P.S) && ((long)j - i < (long)P.mask_off);
-                const float p = vis ? exp2f((s_[r] - s_lse[il]) * LOG2E) : 0.f;
-                const float dm = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)i) * (uint32_t)P.S + (uint32_t)j);
+                float e = fmaf(s_[r], LOG2E, l4[r]);
+                if (edge) e = (ib + r >= ilo && ib + r < P.T) ? e : -INFINITY;
+                const float p = fast_exp2(e);
+                float dm = 1.f;
+                if (dropping) dm = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
                 pd[u][r] = p * dm;
-                ds[u][r] = p * (dp[r] * dm - s_del[il]);
+                ds[u][r] = p * (dp[r] * dm - d4[r]);
             }
         }
 #pragma unroll
@@ -402,20 +436,16 @@ int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S,
         const bpm_attn_problem& q = probs[i];
         AProb& p = g.p[i];
         if (q.B < 1 || q.H < 1 || q.T < 1 || q.S < 1 || q.dh < 1 || q.dh > q.dhp) return BPM_ERR_ARG;
+        if (q.T > (1 << 24) || q.S > (1 << 24)) return BPM_ERR_ARG;      // index arithmetic is 32-bit
         if (q.dhp != probs[0].dhp) return BPM_ERR_ARG;
         p.Q = (const char*)q.Q; p.K = (const char*)q.K; p.V = (const char*)q.V;
         p.O = (char*)q.O; p.ldo = q.ldo; p.lse = q.lse;
         p.dO = (const char*)q.dO; p.delta = q.delta;
         p.dQ = (char*)q.dQ; p.lddq = q.lddq; p.dK = (char*)q.dK; p.lddk = q.lddk; p.dV = (char*)q.dV; p.lddv = q.lddv;
         p.B = q.B; p.H = q.H; p.T = q.T; p.S = q.S; p.dh = q.dh;
-        p.mask_off = q.mask_off > 0 ? q.mask_off : (1 << 30);
+        p.mask_off = (q.mask_off > 0 && q.mask_off < (1 << 29)) ? q.mask_off : (1 << 29);
         p.dq_scale = q.dq_scale;
-        p.drop.thresh = 0; p.drop.key = 0; p.drop.inv_keep = 1.f;
-        if (q.drop_p > 0.f) {
-            p.drop.thresh = (uint32_t)(q.drop_p * 16777216.0 + 0.5);
-            p.drop.key = bpm_host_drop_key(seed, q.drop_site);
-            p.drop.inv_keep = 1.f / (1.f - q.drop_p);
-        }
+        p.drop = bpm_make_drop(q.drop_p, seed, q.drop_site);
         p.nblk = ((blocks_over_S ? q.S : q.T) + 63) / 64;
         p.blk0 = blk;
         blk += p.nblk * q.B * q.H;

@@ -24,11 +24,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 // Counter-hash dropout.  keep(idx) is a pure function of (seed, site, idx), so
 // forward and backward kernels with different tilings regenerate one mask.
-// 24-bit threshold: P(drop) = round(p * 2^24) / 2^24.
+// One 32-bit hash serves TWO consecutive elements (idx >> 1; the low / high 16 bits decide element
+// idx & 1 = 0 / 1), halving the integer work of every epilogue: P(drop) = round(p * 2^16) / 2^16.
 // ---------------------------------------------------------------------------
 struct DropCfg {
     uint32_t key;     // mixed (seed, site); 0 with thresh 0 when disabled
-    uint32_t thresh;  // drop when (hash >> 8) < thresh
+    uint32_t thresh;  // drop when the element's 16 hash bits < thresh
     float inv_keep;   // 1 / (1 - p)
 };
 
@@ -49,10 +50,28 @@ static inline uint32_t bpm_host_drop_key(uint64_t seed, uint32_t site) {
     z ^= z >> 31;
     return (uint32_t)(z ^ (z >> 32));
 }
+static inline DropCfg bpm_make_drop(float p, uint64_t seed, uint32_t site) {
+    DropCfg d;
+    d.thresh = 0; d.key = 0; d.inv_keep = 1.f;
+    if (p > 0.f) {
+        d.thresh = (uint32_t)(p * 65536.0 + 0.5);
+        d.key = bpm_host_drop_key(seed, site);
+        d.inv_keep = 1.f / (1.f - p);
+    }
+    return d;
+}
 // multiplier applied to a kept element; 0 for a dropped one
 BPM_DEV float bpm_drop_mult(const DropCfg& d, uint32_t idx) {
     if (d.thresh == 0) return 1.0f;
-    return ((bpm_hash32(idx, d.key) >> 8) < d.thresh) ? 0.0f : d.inv_keep;
+    const uint32_t h = bpm_hash32(idx >> 1, d.key);
+    const uint32_t bits = (idx & 1u) ? (h >> 16) : (h & 0xFFFFu);
+    return bits < d.thresh ? 0.0f : d.inv_keep;
+}
+// the pair (idx_even, idx_even + 1) with one hash; idx_even must be even
+BPM_DEV void bpm_drop_mult2(const DropCfg& d, uint32_t idx_even, float& m0, float& m1) {
+    const uint32_t h = bpm_hash32(idx_even >> 1, d.key);
+    m0 = (h & 0xFFFFu) < d.thresh ? 0.0f : d.inv_keep;
+    m1 = (h >> 16) < d.thresh ? 0.0f : d.inv_keep;
 }
 
 // ---------------------------------------------------------------------------

@@ -18,16 +18,7 @@ constexpr int NT = 256;
 
 template <typename CT> BPM_DEV void put(void* p, size_t i, float v) { ((CT*)p)[i] = Tr<CT>::from_f(v); }
 
-inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
-    DropCfg d;
-    d.thresh = 0; d.key = 0; d.inv_keep = 1.f;
-    if (p > 0.f) {
-        d.thresh = (uint32_t)(p * 16777216.0 + 0.5);
-        d.key = bpm_host_drop_key(seed, site);
-        d.inv_keep = 1.f / (1.f - p);
-    }
-    return d;
-}
+inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) { return bpm_make_drop(p, seed, site); }
 
 inline unsigned blocks_for(size_t n, int per_block, unsigned cap) {
     size_t g = (n + per_block - 1) / per_block;

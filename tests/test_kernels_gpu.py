@@ -60,14 +60,15 @@ def drop_mult(shape, p, seed, site):
         return torch.ones(shape)
     n = int(np.prod(shape))
     idx = np.arange(n, dtype=np.uint64)
-    h = (idx * 0x9E3779B1 + host_key(seed, site)) & 0xFFFFFFFF
+    odd = (idx & 1).astype(bool)
+    h = ((idx >> 1) * 0x9E3779B1 + host_key(seed, site)) & 0xFFFFFFFF
     h ^= h >> 16
     h = (h * 0x85EBCA6B) & 0xFFFFFFFF
     h ^= h >> 13
     h = (h * 0xC2B2AE35) & 0xFFFFFFFF
     h ^= h >> 16
-    thresh = int(p * 16777216.0 + 0.5)
-    keep = (h >> 8) >= thresh
+    thresh = int(p * 65536.0 + 0.5)
+    keep = np.where(odd, h >> 16, h & 0xFFFF) >= thresh
     return torch.from_numpy(np.where(keep, 1.0 / (1.0 - p), 0.0).astype(np.float32)).reshape(shape)
 
 
