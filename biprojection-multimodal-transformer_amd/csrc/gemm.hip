@@ -9,51 +9,60 @@
 //   TN: X = A[K,M] (m contiguous), Y = B[K,N] (n contiguous)   wgrad    dW = dy^T x
 // Operands are CT (= float: exact f32 MFMA 16x16x4, or bf16: MFMA 16x16x32,
 // f32 accumulate) in row-major buffers whose leading dimension is a multiple
-// of 32 elements with zero padding, so tiles are moved in whole 16-byte
-// chunks with chunk-granular guards only.
+// of 32 elements with zero padding, so tiles move in whole 16-byte chunks.
 //
-// Tile: 128(M) x 64(N) per 256-thread workgroup, 4 waves as 2x2, each wave
-// 64x32 = 4x2 MFMA tiles.  k is consumed one or two 64-byte k-steps per stage
-// through double-buffered, register-staged LDS images:
-//   k-contiguous operand  -> image [rows][stage bytes + 16 B pad]  read with ds_read_b128
-//   k-strided   operand  -> image [k][rows*sz + pad]        read transposed
-//                            (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32)
+// Two kernels share one epilogue:
+//
+// * gemm_tiled_kernel -- the general one.  128(M) x 64(N) tile per 256-thread
+//   workgroup (4 waves as 2x2, each 64x32 = 4x2 MFMA tiles), k consumed one or
+//   two 64-byte k-steps per stage through double-buffered, register-staged LDS
+//   images: k-contiguous operands as 64-byte rows with an XOR swizzle that is
+//   conflict free for ds_read_b128's lane groups, k-strided operands as
+//   [k][rows] images read transposed (ds_read_b64_tr_b16 / ds_read_b32).
+//
+// * gemm_astat_kernel -- "A stationary", for NT / NN products whose whole K
+//   extent is at most 640 bytes per row (hidden size 300 in bf16: every
+//   projection, fc1 and their data gradients).  Ablations of the tiled kernel
+//   at those shapes (tools/bench_kernels.py) showed the time
+//   going to per-workgroup fixed cost and the epilogue, not to MFMA or loads:
+//   with K = 300 a tile has only 5-10 k-iterations.  Here a wave loads its 32
+//   rows of A ONCE, straight into registers as MFMA operand chunks (80 VGPRs),
+//   and the workgroup then walks a range of N tiles, streaming only the weight
+//   tile (L2 resident) through a double-buffered LDS image and running the
+//   epilogue per N tile: 5-19x fewer workgroups, A read once, one barrier per
+//   128 x 64 x K block of MFMAs instead of one per 32 of k.
+//
 // The MFMA is issued "swapped" (Y rows as the A operand, X rows as the B
 // operand) so that a lane owns 4 consecutive n of one output row m and the
-// epilogue stores 16 B (f32) / 8 B (bf16) vectors.
+// epilogue moves 16 B (f32) / 8 B (bf16) vectors.
 //
 // Epilogue (all optional, per problem): + bias[n], + bias[m], * alpha, ReLU,
-// gate by (aux > 0) * s (ReLU/dropout backward), dropout, + residual, then
-// store as f32 row-major (optionally += or atomicAdd for split-K), CT
-// row-major (pad columns zeroed) or CT head-major [B,H,T,dhp] (attention
-// operand layout).
+// gate by (aux > 0) * s (ReLU/dropout backward), dropout, column sums (bias
+// gradients), + residual, then store as f32 row-major (optionally += ; float
+// atomics only for split-K), CT row-major (pad columns zeroed) or CT
+// head-major [B,H,T,dhp] (attention operand layout).
+#include <cstdlib>
+
 #include "bpm_common.h"
 #include "bpm_prof.h"
 #include "../../include/bpmult_hip.h"
 
 namespace {
 
-#ifndef BPM_GEMM_BM
-#define BPM_GEMM_BM 128
-#endif
-#ifndef BPM_GEMM_BN
-#define BPM_GEMM_BN 64
-#endif
-#ifndef BPM_GEMM_WM
-#define BPM_GEMM_WM 2
-#endif
-#ifndef BPM_GEMM_WN
-#define BPM_GEMM_WN 2
-#endif
-constexpr int BM = BPM_GEMM_BM, BN = BPM_GEMM_BN, WM = BPM_GEMM_WM, WN = BPM_GEMM_WN;
+constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
 constexpr int NTHREADS = 64 * WM * WN;
 constexpr int TM = BM / WM / 16;          // 4 MFMA tiles along m per wave
 constexpr int TN = BN / WN / 16;          // 2 along n
-// 64-byte k-steps per LDS stage.  Measured on MI355X at the model's shapes (tools/bench_kernels.py):
-// the forward / dgrad GEMMs have short k loops (K = 300) and are latency bound, so the smaller stage
-// (27 KB of LDS, 5 workgroups per CU in flight) wins by 25-50 %; the weight-gradient GEMM (K = T*B rows)
-// prefers the longer stage.
+// 64-byte k-steps per LDS stage of the tiled kernel.  Measured on MI355X at the model's shapes: the
+// forward / dgrad GEMMs with short k loops are latency bound and the smaller stage (12 KB, 5 workgroups
+// per CU) wins by 25-50 %; the weight-gradient GEMM (K = T*B rows) prefers the longer stage.
 constexpr int KS_FWD = 1, KS_WGRAD = 2;
+// A-stationary kernel: up to 10 k-steps (640 bytes of k per row) held in registers
+constexpr int AS_KS = 10;
+constexpr int AS_BM = 128;                // 4 waves x 32 rows
+// N tile of the streamed weight image: the k-strided (NN) image is [320 k][N tile], so it takes the narrower tile
+// to keep two buffers within 60 KB (two workgroups per CU)
+constexpr int AS_BN_NT = 64, AS_BN_NN = 32;
 
 struct Prob {
     const char* X; const char* Y; char* C;
@@ -68,7 +77,8 @@ struct Prob {
     int flags;
     int out_kind;
     int hB, hH, hT, hdh, hdhp;
-    int tile0, tiles_m, tiles_n, splitk;
+    int tile0, tiles_m, tiles_n, splitk;   // astat: tiles_n = N tiles per workgroup, splitk = number of N ranges
+    int splitk_is_one;                     // no split-K (always true for the A-stationary kernel)
 };
 
 struct Group {
@@ -77,6 +87,235 @@ struct Group {
     Prob p[BPM_MAX_GROUP];
 };
 
+BPM_DEV int swz4(int row) { return (-(row >> 2)) & 3; }
+
+// ---------------------------------------------------------------------------
+// shared epilogue: one 16x16 accumulator tile (lane: row m, columns nb..nb+3)
+// ---------------------------------------------------------------------------
+template <typename CT>
+BPM_DEV void store_ct4(char* C, size_t off_elems, const float (&v)[4], int nvalid) {
+    CT* p = (CT*)C + off_elems;
+    if (nvalid == 4 && ((off_elems & 3) == 0)) {
+        if constexpr (sizeof(CT) == 4) {
+            *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            *(bf16x4*)p = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) p[r] = Tr<CT>::from_f(v[r]);
+    }
+}
+
+template <typename CT>
+BPM_DEV void epilogue_tile(const Prob& P, bool lead, int m, int nb, const f32x4& acc, float (&csum)[4]) {
+    if (m >= P.M) return;
+    const bool atomic = (P.flags & BPM_GEMM_ATOMIC) != 0;
+    const bool accum = (P.flags & BPM_GEMM_ACCUM) != 0;
+    const bool relu = (P.flags & BPM_GEMM_RELU) != 0;
+    const bool full = nb + 3 < P.N;
+    float v[4];
+    // side operands: one 16-byte (f32) / 8-byte (bf16) load per lane where the 4 columns are in range and aligned
+    float bn[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {1.f, 1.f, 1.f, 1.f};
+    if (lead && P.bias_n) {
+        const float* bp = P.bias_n + nb;
+        if (full && (((uintptr_t)bp & 15) == 0)) { const f32x4 t = *(const f32x4*)bp; bn[0] = t[0]; bn[1] = t[1]; bn[2] = t[2]; bn[3] = t[3]; }
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (nb + q < P.N) bn[q] = bp[q];
+        }
+    }
+    if (lead && P.resid) {
+        const float* rp = P.resid + (size_t)m * P.ldr + nb;
+        if (full && (((uintptr_t)rp & 15) == 0)) { const f32x4 t = *(const f32x4*)rp; rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (nb + q < P.N) rs[q] = rp[q];
+        }
+    }
+    if (P.gate) {
+        const CT* gp = (const CT*)P.gate + (size_t)m * P.ldg + nb;
+        if (nb + 3 < P.ldg) {          // gate rows are padded CT rows: an aligned 4-element read is always in bounds
+            if constexpr (sizeof(CT) == 4) { const f32x4 t = *(const f32x4*)gp; gt[0] = t[0]; gt[1] = t[1]; gt[2] = t[2]; gt[3] = t[3]; }
+            else { const bf16x4 t = *(const bf16x4*)gp; gt[0] = (float)t[0]; gt[1] = (float)t[1]; gt[2] = (float)t[2]; gt[3] = (float)t[3]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (nb + q < P.N) gt[q] = Tr<CT>::to_f(gp[q]);
+        }
+    }
+    const float bm = (lead && P.bias_m) ? P.bias_m[m] : 0.f;
+    float dm[4] = {1.f, 1.f, 1.f, 1.f};
+    if (P.drop.thresh != 0) {
+        const uint32_t i0 = (uint32_t)m * (uint32_t)P.N + (uint32_t)nb;
+        if ((i0 & 1u) == 0) {                       // (nb, nb+1) and (nb+2, nb+3) are hash pairs
+            bpm_drop_mult2(P.drop, i0, dm[0], dm[1]);
+            bpm_drop_mult2(P.drop, i0 + 2, dm[2], dm[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dm[q] = bpm_drop_mult(P.drop, i0 + q);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = 0.f;
+        if (nb + q < P.N) {
+            x = (acc[q] + bn[q] + bm) * P.alpha;
+            if (relu) x = fmaxf(x, 0.f);
+            if (P.gate) x = gt[q] > 0.f ? x * P.gate_scale : 0.f;
+            x *= dm[q];
+            csum[q] += x;
+            x += rs[q];
+        }
+        v[q] = x;
+    }
+    if (P.out_kind == BPM_OUT_F32) {
+        float* c = (float*)P.C + (size_t)m * P.ldc + nb;
+        if (full && !atomic && (((uintptr_t)c & 15) == 0)) {
+            f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+            if (accum) o += *(const f32x4*)c;
+            *(f32x4*)c = o;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (nb + q >= P.N) continue;
+                if (atomic) atomicAdd(c + q, v[q]);
+                else if (accum) c[q] += v[q];
+                else c[q] = v[q];
+            }
+        }
+    } else if (P.out_kind == BPM_OUT_CT) {
+        const int nvalid = min(4, P.ldc - nb);   // pad columns [N, ldc) get zeros
+        if (nvalid > 0) store_ct4<CT>(P.C, (size_t)m * P.ldc + nb, v, nvalid);
+    } else {  // BPM_OUT_HEADS: m = t*B + b, n = h*dh + c  ->  [B,H,T,dhp]
+        const int tt = m / P.hB, bb = m % P.hB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = nb + q;
+            if (n >= P.N) continue;
+            const int h = n / P.hdh, c = n % P.hdh;
+            ((CT*)P.C)[(((size_t)bb * P.hH + h) * P.hT + tt) * P.hdhp + c] = Tr<CT>::from_f(v[q]);
+        }
+    }
+}
+
+// column sums of a wave's tiles: reduce over the 16 row lanes, one atomic per column
+BPM_DEV void flush_colsum(const Prob& P, float (&csum)[4], int nb, int r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = csum[q];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        if (r == 0 && nb + q < P.N) atomicAdd(P.colsum + nb + q, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fast epilogue.  The general epilogue_tile above costs ~25 VALU instructions per output element (64-bit
+// address arithmetic per side operand, per-lane alignment tests that diverge, per-element bound tests and two
+// integer divisions per element for the head-major scatter) -- more than the MFMA time of a K = 300 product.
+// When a problem satisfies wave-uniform preconditions (N % 4 == 0, 16-byte aligned side operands with
+// leading dimensions % 4 == 0, no split-K / atomics / row bias) the same arithmetic is done with the
+// row-invariant part hoisted per output row and straight-line 4-wide code per tile.
+// ---------------------------------------------------------------------------
+BPM_DEV bool epi_fast_ok(const Prob& P) {
+    const uintptr_t al = (uintptr_t)P.bias_n | (uintptr_t)P.resid | (uintptr_t)P.C | (uintptr_t)P.gate;
+    return (P.N & 3) == 0 && (al & 15) == 0 && ((P.ldr | P.ldc | P.ldg) & 3) == 0 && !P.bias_m &&
+           !(P.flags & BPM_GEMM_ATOMIC) && P.splitk_is_one;
+}
+
+struct EpiRow {            // per output row m: everything that does not depend on the column
+    bool ok;
+    uint32_t offc, offr, offg, didx;   // m*ldc, m*ldr, m*ldg, m*N
+    uint32_t hrow;                     // head-major: (b*H*T + t) * dhp
+};
+
+BPM_DEV EpiRow epi_row(const Prob& P, int m) {
+    EpiRow e;
+    e.ok = m < P.M;
+    const uint32_t um = (uint32_t)(e.ok ? m : 0);
+    e.offc = um * (uint32_t)P.ldc; e.offr = um * (uint32_t)P.ldr; e.offg = um * (uint32_t)P.ldg; e.didx = um * (uint32_t)P.N;
+    e.hrow = 0;
+    if (P.out_kind == BPM_OUT_HEADS) {
+        const uint32_t tt = um / (uint32_t)P.hB, bb = um - tt * (uint32_t)P.hB;
+        e.hrow = (bb * (uint32_t)(P.hH * P.hT) + tt) * (uint32_t)P.hdhp;
+    }
+    return e;
+}
+
+template <typename CT>
+BPM_DEV void epilogue_fast(const Prob& P, const EpiRow& e, int nb, f32x4 x, f32x4& csum) {
+    const bool valid = e.ok && nb < P.N;               // N % 4 == 0: a lane's 4 columns are all in or all out
+    if (valid) {
+        if (P.bias_n) x += *(const f32x4*)(P.bias_n + nb);
+        if (P.alpha != 1.f) x *= P.alpha;
+        if (P.flags & BPM_GEMM_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = fmaxf(x[q], 0.f);
+        }
+        if (P.gate) {
+            f32x4 gt;
+            if constexpr (sizeof(CT) == 4) gt = *(const f32x4*)((const float*)P.gate + e.offg + nb);
+            else { const bf16x4 t = *(const bf16x4*)((const bf16_t*)P.gate + e.offg + nb); gt = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = gt[q] > 0.f ? x[q] * P.gate_scale : 0.f;
+        }
+        if (P.drop.thresh != 0) {                       // m*N + nb is even: two hash pairs
+            float d0, d1, d2, d3;
+            bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb, d0, d1);
+            bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb + 2u, d2, d3);
+            x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
+        }
+        csum += x;
+        if (P.resid) x += *(const f32x4*)(P.resid + e.offr + nb);
+    }
+    if (P.out_kind == BPM_OUT_F32) {
+        if (!valid) return;
+        float* c = (float*)P.C + e.offc + nb;
+        if (P.flags & BPM_GEMM_ACCUM) x += *(const f32x4*)c;
+        *(f32x4*)c = x;
+    } else if (P.out_kind == BPM_OUT_CT) {
+        if (!e.ok || nb >= P.ldc) return;               // pad columns [N, ldc) receive zeros
+        if (!valid) x = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (sizeof(CT) == 4) *(f32x4*)((float*)P.C + e.offc + nb) = x;
+        else { bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3]; *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o; }
+    } else {                                            // head-major: one division per tile, heads advance by carry
+        if (!valid) return;
+        uint32_t h = (uint32_t)nb / (uint32_t)P.hdh, c = (uint32_t)nb - h * (uint32_t)P.hdh;
+        const uint32_t hstride = (uint32_t)(P.hT * P.hdhp);
+        CT* base = (CT*)P.C + e.hrow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            base[h * hstride + c] = Tr<CT>::from_f(x[q]);
+            if (++c == (uint32_t)P.hdh) { c = 0; ++h; }
+        }
+    }
+}
+
+// one wave's column block: rows (m0 + 16*b + r), b < NB, columns nb..nb+3
+template <typename CT, int NB>
+BPM_DEV void epilogue_cols(const Prob& P, bool fast, bool lead, int m0, int r, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB]) {
+    if (fast) {
+        f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NB; ++b) epilogue_fast<CT>(P, rows[b], nb, acc[b], cs);
+        if (P.colsum) { float c4[4] = {cs[0], cs[1], cs[2], cs[3]}; flush_colsum(P, c4, nb, r); }
+    } else {
+        float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NB; ++b) epilogue_tile<CT>(P, lead, m0 + 16 * b + r, nb, acc[b], csum);
+        if (P.colsum) flush_colsum(P, csum, nb, r);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS images of the tiled kernel
+// ---------------------------------------------------------------------------
 // PERM (bf16, k-contiguous, one k-step per stage): the other operand of this product is read TRANSPOSED with the
 // conflict-free "ctile" row assignment (lane group g takes k = 4g..4g+3 and 16+4g..16+4g+3), so this image stores
 // the eight 8-byte halves of a 64-byte k-step re-ordered: half h -> chunk (h & 3), slot (h >> 2).  One
@@ -85,13 +324,12 @@ template <typename CT, bool KCONTIG, int ROWS, int KSTEPS, bool PERM = false>
 struct Side {
     static constexpr int BKB = KSTEPS * 64;          // bytes of k per stage and row
     // k-contiguous image.  One k-step per stage: rows of exactly 64 B with the 16-byte chunk index XOR-swizzled
-    // by swz(row): ds_read_b128 serves lanes in groups {0-3,12-15,20-27},{4-11,16-19,28-31},.. (MI355X_MICROARCH
-    // section LDS), i.e. 16 rows with the chunk alternating between g and g^1; swz = (-(row>>2))&3 puts those 16
+    // by swz4(row): ds_read_b128 serves lanes in groups {0-3,12-15,20-27},{4-11,16-19,28-31},.. (MI355X_MICROARCH
+    // section LDS), i.e. 16 rows with the chunk alternating between g and g^1; swz4 = (-(row>>2))&3 puts those 16
     // addresses on 16 distinct 16-byte slots of the 256-byte bank row (a +16 B row pad does not: measured
     // SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).  Longer stages keep the padded rows.
     static constexpr bool SWZ = (KSTEPS == 1);
     static constexpr int ROW_STRIDE = SWZ ? 64 : BKB + 16;
-    static BPM_DEV int swz(int row) { return (-(row >> 2)) & 3; }
     static constexpr int SZ = sizeof(CT);
     static constexpr int EPC = Tr<CT>::EPC;
     static constexpr int BK = KSTEPS * Tr<CT>::KSTEP;                    // elements of k per stage
@@ -100,9 +338,8 @@ struct Side {
     static constexpr int NCHUNK = ROWS * BKB / 16;
     static constexpr int PER_THREAD = (NCHUNK + NTHREADS - 1) / NTHREADS;
 
-    // global -> registers.  rows_bound: valid rows of this side (M or N);
-    // k_lo/k_hi: contraction range of this block; ld: leading dim (elements).
-    static BPM_DEV void load(const char* base, int ld, int row0, int rows_bound, int k0, int k_hi, int kext,
+    // global -> registers.  rows_bound: valid rows of this side (M or N); k_hi: contraction bound; ld: leading dim.
+    static BPM_DEV void load(const char* base, int ld, int row0, int rows_bound, int k0, int k_hi,
                              u32x4 (&reg)[PER_THREAD], int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
@@ -112,7 +349,7 @@ struct Side {
             if (KCONTIG) {
                 const int row = c / (BKB / 16), kc = c % (BKB / 16);
                 const int k = k0 + kc * EPC;
-                ok = (row0 + row < rows_bound) && (k < k_hi) && (k < kext);
+                ok = (row0 + row < rows_bound) && (k < k_hi);
                 off = ((size_t)(row0 + row) * ld + k) * SZ;
             } else {
                 constexpr int CPR = ROWS * SZ / 16;
@@ -135,13 +372,13 @@ struct Side {
                 const int row = c / (BKB / 16), kc = c % (BKB / 16);
                 if constexpr (PERM && sizeof(CT) == 2) {
                     static_assert(!PERM || KSTEPS == 1, "PERM images hold one k-step");
-                    const int h0 = 2 * kc, h1 = 2 * kc + 1, sw = swz(row);
+                    const int h0 = 2 * kc, h1 = 2 * kc + 1, sw = swz4(row);
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                     *(u32x2*)(img + row * 64 + (((h0 & 3) ^ sw) << 4) + ((h0 >> 2) << 3)) = u32x2{reg[i][0], reg[i][1]};
                     *(u32x2*)(img + row * 64 + (((h1 & 3) ^ sw) << 4) + ((h1 >> 2) << 3)) = u32x2{reg[i][2], reg[i][3]};
                     continue;
                 }
-                dst = row * ROW_STRIDE + (SWZ ? (kc ^ swz(row)) : kc) * 16;
+                dst = row * ROW_STRIDE + (SWZ ? (kc ^ swz4(row)) : kc) * 16;
             } else {
                 constexpr int CPR = ROWS * SZ / 16;
                 const int kr = c / CPR, cc = c % CPR;
@@ -155,7 +392,7 @@ struct Side {
         if (KCONTIG) {
             if (SWZ) {
                 const int r = lane & 15, g = lane >> 4;
-                return *(const typename Tr<CT>::frag*)(img + (r0 + r) * 64 + ((g ^ swz(r0 + r)) << 4));
+                return *(const typename Tr<CT>::frag*)(img + (r0 + r) * 64 + ((g ^ swz4(r0 + r)) << 4));
             }
             return read_rowfrag<CT>(img, ROW_STRIDE, r0, ks, lane);
         }
@@ -165,27 +402,20 @@ struct Side {
     }
 };
 
-template <typename CT>
-BPM_DEV void store_ct4(char* C, size_t off_elems, const float (&v)[4], int nvalid) {
-    CT* p = (CT*)C + off_elems;
-    if (nvalid == 4 && ((off_elems & 3) == 0)) {
-        if constexpr (sizeof(CT) == 4) {
-            *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-            *(bf16x4*)p = o;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) p[r] = Tr<CT>::from_f(v[r]);
-    }
+BPM_DEV const Prob& pick_problem(const Group& grp, int& bid) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < grp.nprob; ++i)
+        if (bid >= grp.p[i].tile0) pi = i;
+    bid -= grp.p[pi].tile0;
+    return grp.p[pi];
 }
 
+// ---------------------------------------------------------------------------
+// general tiled kernel
+// ---------------------------------------------------------------------------
 template <typename CT, bool XK, bool YK, int KSTEPS>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
+__global__ __launch_bounds__(NTHREADS) void gemm_tiled_kernel(const Group grp) {
     typedef Side<CT, XK, BM, KSTEPS, XK && !YK> SX;     // NN: X is k-contiguous beside a transposed-read Y
     typedef Side<CT, YK, BN, KSTEPS, false> SY;
     constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
@@ -194,14 +424,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // block -> (problem, split, tile)
     int bid = blockIdx.x;
-    int pi = 0;
-#pragma unroll 1
-    for (int i = 1; i < grp.nprob; ++i)
-        if (bid >= grp.p[i].tile0) pi = i;
-    const Prob& P = grp.p[pi];
-    bid -= P.tile0;
+    const Prob& P = pick_problem(grp, bid);
     const int tiles = P.tiles_m * P.tiles_n;
     const int split = bid / tiles;
     const int t = bid % tiles;
@@ -212,7 +436,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
     const int per = (nkt_all + P.splitk - 1) / P.splitk;
     const int kt_lo = split * per;
     const int kt_hi = min(nkt_all, kt_lo + per);
-    const int kext = (P.K + Tr<CT>::EPC - 1) / Tr<CT>::EPC * Tr<CT>::EPC;
 
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -222,8 +445,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
 
     u32x4 rx[SX::PER_THREAD], ry[SY::PER_THREAD];
     if (kt_lo < kt_hi) {
-        SX::load(P.X, P.ldx, m0, P.M, kt_lo * BK, P.K, kext, rx, tid);
-        SY::load(P.Y, P.ldy, n0, P.N, kt_lo * BK, P.K, kext, ry, tid);
+        SX::load(P.X, P.ldx, m0, P.M, kt_lo * BK, P.K, rx, tid);
+        SY::load(P.Y, P.ldy, n0, P.N, kt_lo * BK, P.K, ry, tid);
         SX::store(smem, rx, tid);
         SY::store(smem + SX::IMG_BYTES, ry, tid);
     }
@@ -232,13 +455,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
 #pragma unroll 1
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const bool more = kt + 1 < kt_hi;
-#ifdef BPM_EXP_NOLOAD
-        if (false) {
-#else
         if (more) {
-#endif
-            SX::load(P.X, P.ldx, m0, P.M, (kt + 1) * BK, P.K, kext, rx, tid);
-            SY::load(P.Y, P.ldy, n0, P.N, (kt + 1) * BK, P.K, kext, ry, tid);
+            SX::load(P.X, P.ldx, m0, P.M, (kt + 1) * BK, P.K, rx, tid);
+            SY::load(P.Y, P.ldy, n0, P.N, (kt + 1) * BK, P.K, ry, tid);
         }
         const char* ix = smem + cur * STAGE;
         const char* iy = ix + SX::IMG_BYTES;
@@ -252,13 +471,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
-                for (int b = 0; b < TM; ++b) {
-#ifndef BPM_EXP_NOMMA
-                    acc[a][b] = Tr<CT>::mma(fy[a], fx[b], acc[a][b]);
-#else
-                    asm volatile("" :: "v"(fy[a]), "v"(fx[b]));
-#endif
-                }
+                for (int b = 0; b < TM; ++b) acc[a][b] = Tr<CT>::mma(fy[a], fx[b], acc[a][b]);
         }
         if (more) {
             char* nx = smem + (cur ^ 1) * STAGE;
@@ -269,143 +482,178 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const Group grp) {
         cur ^= 1;
     }
 
-    // ---------------- epilogue ----------------
-#ifdef BPM_EXP_NOEPI
-    if (acc[0][0][0] == 12345.678f) ((float*)P.C)[0] = acc[0][0][1];
-    return;
-#endif
     const int r = lane & 15, g = lane >> 4;
     const bool lead = (split == 0);
-    const bool atomic = (P.flags & BPM_GEMM_ATOMIC) != 0;
-    const bool accum = (P.flags & BPM_GEMM_ACCUM) != 0;
-    const bool relu = (P.flags & BPM_GEMM_RELU) != 0;
     if (kt_lo >= kt_hi && !lead) return;
-    float csum[TN][4];
+    const bool fast = epi_fast_ok(P);                   // wave-uniform
+    const int mw = m0 + wm * (BM / WM);
+    EpiRow rows[TM];
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+    for (int b = 0; b < TM; ++b) rows[b] = epi_row(P, mw + 16 * b + r);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) csum[a][q] = 0.f;
+    for (int a = 0; a < TN; ++a)       // colsum shuffles: uniform per workgroup, every lane takes part
+        epilogue_cols<CT, TM>(P, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows);
+}
+
+// ---------------------------------------------------------------------------
+// A-stationary kernel (NT / NN with K*sizeof(CT) <= 640)
+// ---------------------------------------------------------------------------
+template <typename CT, bool YK, int ABN>
+struct AsW {                                   // LDS image of one weight tile: ABN n-rows (or columns) x all of K
+    static constexpr int SZ = sizeof(CT);
+    static constexpr int EPC = Tr<CT>::EPC;
+    static constexpr int KROWS = AS_KS * Tr<CT>::KSTEP;                       // k elements held
+    // YK: [ks][n][64 B] swizzled sub-images (4 KB per k-step);  !YK: [k][ABN*sz + pad] for transposed reads
+    static constexpr int TSTRIDE = ABN * SZ + Tr<CT>::TR_PAD_B;
+    static constexpr int IMG_BYTES = YK ? AS_KS * ABN * 64 : KROWS * TSTRIDE;
+    static constexpr int NCHUNK = YK ? AS_KS * ABN * 4 : KROWS * (ABN * SZ / 16);
+    static constexpr int PER_THREAD = (NCHUNK + NTHREADS - 1) / NTHREADS;
+
+    static BPM_DEV void load(const Prob& P, int n0, int nks, u32x4 (&reg)[PER_THREAD], int tid) {
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * (BM / WM) + 16 * b + r;
-        if (m >= P.M) continue;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int nb = n0 + wn * (BN / WN) + 16 * a + 4 * g;
-            float v[4];
-            const bool full = nb + 3 < P.N;
-            // side operands: one 16-byte (f32) / 8-byte (bf16) load per lane where the 4 columns are in range and aligned
-            float bn[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {1.f, 1.f, 1.f, 1.f};
-            if (lead && P.bias_n) {
-                const float* bp = P.bias_n + nb;
-                if (full && (((uintptr_t)bp & 15) == 0)) { const f32x4 t = *(const f32x4*)bp; bn[0] = t[0]; bn[1] = t[1]; bn[2] = t[2]; bn[3] = t[3]; }
-                else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (nb + q < P.N) bn[q] = bp[q];
-                }
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NTHREADS;
+            bool ok = c < NCHUNK;
+            size_t off;
+            if (YK) {                       // chunk c -> k-step ks, row n, 16-byte chunk kc of W[n][k]
+                const int ks = c / (ABN * 4), rem = c % (ABN * 4);
+                const int n = rem >> 2, kc = rem & 3;
+                const int k = ks * Tr<CT>::KSTEP + kc * EPC;
+                ok = ok && (ks < nks) && (n0 + n < P.N) && (k < P.K);
+                off = ((size_t)(n0 + n) * P.ldy + k) * SZ;
+            } else {                        // chunk c -> k row kr, 16-byte chunk cc of B[k][n]
+                constexpr int CPR = ABN * SZ / 16;
+                const int kr = c / CPR, cc = c % CPR;
+                const int col = n0 + cc * EPC;
+                ok = ok && (kr < P.K) && (col + EPC <= P.ldy) && (col < P.N);
+                off = ((size_t)kr * P.ldy + col) * SZ;
             }
-            if (lead && P.resid) {
-                const float* rp = P.resid + (size_t)m * P.ldr + nb;
-                if (full && (((uintptr_t)rp & 15) == 0)) { const f32x4 t = *(const f32x4*)rp; rs[0] = t[0]; rs[1] = t[1]; rs[2] = t[2]; rs[3] = t[3]; }
-                else {
+            reg[i] = ok ? *(const u32x4*)(P.Y + off) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    static BPM_DEV void store(char* img, const u32x4 (&reg)[PER_THREAD], int tid) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (nb + q < P.N) rs[q] = rp[q];
-                }
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NTHREADS;
+            if (c >= NCHUNK) continue;
+            int dst;
+            if (YK) {
+                const int ks = c / (ABN * 4), rem = c % (ABN * 4);
+                const int n = rem >> 2, kc = rem & 3;
+                dst = ks * (ABN * 64) + n * 64 + ((kc ^ swz4(n)) << 4);
+            } else {
+                constexpr int CPR = ABN * SZ / 16;
+                dst = (c / CPR) * TSTRIDE + (c % CPR) * 16;
             }
-            if (P.gate) {
-                const CT* gp = (const CT*)P.gate + (size_t)m * P.ldg + nb;
-                if (nb + 3 < P.ldg) {          // gate rows are padded CT rows: an aligned 4-element read is always in bounds
-                    if constexpr (sizeof(CT) == 4) { const f32x4 t = *(const f32x4*)gp; gt[0] = t[0]; gt[1] = t[1]; gt[2] = t[2]; gt[3] = t[3]; }
-                    else { const bf16x4 t = *(const bf16x4*)gp; gt[0] = (float)t[0]; gt[1] = (float)t[1]; gt[2] = (float)t[2]; gt[3] = (float)t[3]; }
-                } else {
+            *(u32x4*)(img + dst) = reg[i];
+        }
+    }
+    static BPM_DEV typename Tr<CT>::frag frag(const char* img, int n0w, int ks, int lane) {
+        if (YK) {
+            const int r = lane & 15, g = lane >> 4;
+            return *(const typename Tr<CT>::frag*)(img + ks * (ABN * 64) + (n0w + r) * 64 + ((g ^ swz4(n0w + r)) << 4));
+        }
+        return Tr<CT>::read_tr(img, TSTRIDE, ks * Tr<CT>::KSTEP, n0w, lane, Tr<CT>::TR_CTILE);
+    }
+};
+
+// A operand chunk of k-step ks for row `row`, straight from global memory.  Beside a transposed-read
+// weight image (NN, bf16) the chunk holds k = 4g..4g+3 and 16+4g..16+4g+3 (two 8-byte loads) so that
+// element order matches the "ctile" order of the other operand.
+template <typename CT, bool YK>
+BPM_DEV typename Tr<CT>::frag load_a_chunk(const Prob& P, int row, int ks, int g) {
+    typedef typename Tr<CT>::frag frag;
+    if (row >= P.M || ks * Tr<CT>::KSTEP >= P.K) return Tr<CT>::zero();
+    const char* base = P.X + ((size_t)row * P.ldx) * sizeof(CT) + ks * 64;
+    if constexpr (!YK && sizeof(CT) == 2) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 lo = *(const u32x2*)(base + g * 8), hi = *(const u32x2*)(base + 32 + g * 8);
+        u32x4 v = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        return *(frag*)&v;
+    } else {
+        return *(const frag*)(base + g * 16);
+    }
+}
+
+template <typename CT, bool YK, int ABN>
+__global__ __launch_bounds__(NTHREADS) void gemm_astat_kernel(const Group grp) {
+    typedef AsW<CT, YK, ABN> W;
+    typedef typename Tr<CT>::frag frag;
+    __shared__ __attribute__((aligned(16))) char smem[2 * W::IMG_BYTES];
+    constexpr int MT = AS_BM / 4 / 16;          // 2 m-tiles (32 rows) per wave
+    constexpr int NTW = ABN / 16;               // every wave covers the whole N tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const Prob& P = pick_problem(grp, bid);
+    const int mt = bid / P.splitk, ns = bid % P.splitk;
+    const int m0 = mt * AS_BM + wave * 32;
+    const int ntiles = (P.N + ABN - 1) / ABN;
+    const int nt_lo = ns * P.tiles_n, nt_hi = min(ntiles, nt_lo + P.tiles_n);
+    const int nks = (P.K + Tr<CT>::KSTEP - 1) / Tr<CT>::KSTEP;
+
+    // the wave's rows of A, once, as MFMA operand chunks
+    frag fa[MT][AS_KS];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (nb + q < P.N) gt[q] = Tr<CT>::to_f(gp[q]);
-                }
-            }
-            const float bm = (lead && P.bias_m) ? P.bias_m[m] : 0.f;
-            float dm[4] = {1.f, 1.f, 1.f, 1.f};
-            if (P.drop.thresh != 0) {
-                const uint32_t i0 = (uint32_t)m * (uint32_t)P.N + (uint32_t)nb;
-                if ((i0 & 1u) == 0) {                       // (nb, nb+1) and (nb+2, nb+3) are hash pairs
-                    bpm_drop_mult2(P.drop, i0, dm[0], dm[1]);
-                    bpm_drop_mult2(P.drop, i0 + 2, dm[2], dm[3]);
-                } else {
+    for (int b = 0; b < MT; ++b)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dm[q] = bpm_drop_mult(P.drop, i0 + q);
-                }
-            }
+        for (int ks = 0; ks < AS_KS; ++ks) fa[b][ks] = load_a_chunk<CT, YK>(P, m0 + 16 * b + r, ks, g);
+
+    const bool fast = epi_fast_ok(P);
+    EpiRow rows[MT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = nb + q;
-                float x = 0.f;
-                if (n < P.N) {
-                    x = (acc[a][b][q] + bn[q] + bm) * P.alpha;
-                    if (relu) x = fmaxf(x, 0.f);
-                    if (P.gate) x = gt[q] > 0.f ? x * P.gate_scale : 0.f;
-                    x *= dm[q];
-                    csum[a][q] += x;
-                    x += rs[q];
-                }
-                v[q] = x;
-            }
-#ifdef BPM_EXP_NOSTORE
-            if (v[0] + v[1] + v[2] + v[3] == 12345.678f) ((float*)P.C)[0] = v[0];
-            continue;
-#endif
-            if (P.out_kind == BPM_OUT_F32) {
-                float* c = (float*)P.C + (size_t)m * P.ldc + nb;
-                if (full && !atomic && (((uintptr_t)c & 15) == 0)) {
-                    f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
-                    if (accum) o += *(const f32x4*)c;
-                    *(f32x4*)c = o;
-                } else {
+    for (int b = 0; b < MT; ++b) rows[b] = epi_row(P, m0 + 16 * b + r);
+
+    u32x4 rw[W::PER_THREAD];
+    if (nt_lo < nt_hi) {
+        W::load(P, nt_lo * ABN, nks, rw, tid);
+        W::store(smem, rw, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int nt = nt_lo; nt < nt_hi; ++nt) {
+        const bool more = nt + 1 < nt_hi;
+        if (more) W::load(P, (nt + 1) * ABN, nks, rw, tid);
+        const char* img = smem + cur * W::IMG_BYTES;
+        f32x4 acc[NTW][MT];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (nb + q >= P.N) continue;
-                        if (atomic) atomicAdd(c + q, v[q]);
-                        else if (accum) c[q] += v[q];
-                        else c[q] = v[q];
-                    }
-                }
-            } else if (P.out_kind == BPM_OUT_CT) {
-                const int nvalid = min(4, P.ldc - nb);   // pad columns [N, ldc) get zeros
-                if (nvalid > 0) store_ct4<CT>(P.C, (size_t)m * P.ldc + nb, v, nvalid);
-            } else {  // BPM_OUT_HEADS: m = t*B + b, n = h*dh + c  ->  [B,H,T,dhp]
-                const int tt = m / P.hB, bb = m % P.hB;
+        for (int a = 0; a < NTW; ++a)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nb + q;
-                    if (n >= P.N) continue;
-                    const int h = n / P.hdh, c = n % P.hdh;
-                    ((CT*)P.C)[(((size_t)bb * P.hH + h) * P.hT + tt) * P.hdhp + c] = Tr<CT>::from_f(v[q]);
+            for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < AS_KS; ++ks) {
+            if (ks < nks) {
+#pragma unroll
+                for (int a = 0; a < NTW; ++a) {
+                    const frag fy = W::frag(img, 16 * a, ks, lane);
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) acc[a][b] = Tr<CT>::mma(fy, fa[b][ks], acc[a][b]);
                 }
             }
         }
-    }
-    if (P.colsum) {   // uniform per block: every lane takes part in the shuffles
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = csum[a][q];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                const int n = n0 + wn * (BN / WN) + 16 * a + 4 * g + q;
-                if (r == 0 && n < P.N) atomicAdd(P.colsum + n, v);
-            }
+        for (int a = 0; a < NTW; ++a) epilogue_cols<CT, MT>(P, fast, true, m0, r, nt * ABN + 16 * a + 4 * g, acc[a], rows);
+        if (more) W::store(smem + (cur ^ 1) * W::IMG_BYTES, rw, tid);
+        __syncthreads();
+        cur ^= 1;
     }
 }
 
 template <typename CT>
-int launch(int variant, const Group& g, hipStream_t s) {
+int launch(int variant, bool astat, const Group& g, hipStream_t s) {
     dim3 grid(g.total_tiles), block(NTHREADS);
-    switch (variant) {
-        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<CT, true, true, KS_FWD>), grid, block, 0, s, g); break;
-        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<CT, true, false, KS_FWD>), grid, block, 0, s, g); break;
-        case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<CT, false, false, KS_WGRAD>), grid, block, 0, s, g); break;
-        default: return BPM_ERR_ARG;
+    if (astat) {
+        if (variant == BPM_GEMM_NT) hipLaunchKernelGGL((gemm_astat_kernel<CT, true, AS_BN_NT>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_astat_kernel<CT, false, AS_BN_NN>), grid, block, 0, s, g);
+    } else {
+        switch (variant) {
+            case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD>), grid, block, 0, s, g); break;
+            case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, KS_FWD>), grid, block, 0, s, g); break;
+            case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, KS_WGRAD>), grid, block, 0, s, g); break;
+            default: return BPM_ERR_ARG;
+        }
     }
     BPM_CHECK_LAUNCH();
     return 0;
@@ -415,10 +663,28 @@ int launch(int variant, const Group& g, hipStream_t s) {
 
 extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs, int nprob, uint64_t seed, void* stream) {
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
+    if (variant != BPM_GEMM_NT && variant != BPM_GEMM_NN && variant != BPM_GEMM_TN) return BPM_ERR_ARG;
     const int sz = dtype == BPM_BF16 ? 2 : 4;
+    // A-stationary path: every problem of the launch has its whole K in 10 k-steps and no split-K
+    bool astat = variant != BPM_GEMM_TN;
+    long rows = 0;
+    for (int i = 0; i < nprob; ++i) {
+        if ((long)probs[i].K * sz > AS_KS * 64 || probs[i].splitk > 1 || (probs[i].flags & BPM_GEMM_ATOMIC)) astat = false;
+        rows += probs[i].M;
+    }
+    if (astat && rows < 1024) astat = false;       // tiny launches: nothing to amortise
+    // Measured on MI355X (tools/bench_kernels.py, hidden 300, B*T = 4096 x 6 problems): the A-stationary kernel is
+    // correct (the parity suite runs it in f32 and bf16 with BPM_ASTAT=1) but 1.3-2x SLOWER than the tiled kernel:
+    // both are bound by the exposed memory latency of a depth-1 prefetch, and the tiled kernel hides it with 5
+    // workgroups per CU where this one has 2.  It stays opt-in until its weight stream is prefetched deeper.
+    static const bool use_astat = getenv("BPM_ASTAT") != nullptr;
+    if (!use_astat) astat = false;
     Group g;
     g.nprob = nprob;
     int tile = 0;
+    // N tiles per workgroup of the A-stationary kernel: enough ranges that the launch has >= ~512 workgroups
+    long mtiles = 0;
+    for (int i = 0; i < nprob; ++i) mtiles += (probs[i].M + AS_BM - 1) / AS_BM;
     for (int i = 0; i < nprob; ++i) {
         const bpm_gemm_problem& q = probs[i];
         Prob& p = g.p[i];
@@ -438,18 +704,32 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         p.flags = q.flags; p.out_kind = q.out_kind;
         p.hB = q.heads_B; p.hH = q.heads_H; p.hT = q.heads_T; p.hdh = q.heads_dh; p.hdhp = q.heads_dhp;
         if (q.out_kind == BPM_OUT_HEADS && (q.heads_B < 1 || q.heads_dh < 1 || q.heads_H * q.heads_dh != q.N)) return BPM_ERR_ARG;
-        p.tiles_m = (q.M + BM - 1) / BM;
-        p.tiles_n = (q.N + BN - 1) / BN;
-        if (q.out_kind == BPM_OUT_CT && p.tiles_n * BN < q.ldc) return BPM_ERR_ARG;
-        p.splitk = q.splitk > 1 ? q.splitk : 1;
-        if (p.splitk > 1 && !((q.flags & BPM_GEMM_ATOMIC) && q.out_kind == BPM_OUT_F32)) return BPM_ERR_ARG;
+        const int bn = astat ? (variant == BPM_GEMM_NT ? AS_BN_NT : AS_BN_NN) : BN;
+        const int ntiles = (q.N + bn - 1) / bn;
+        if (q.out_kind == BPM_OUT_CT && ntiles * bn < q.ldc) return BPM_ERR_ARG;
         p.tile0 = tile;
-        tile += p.tiles_m * p.tiles_n * p.splitk;
+        if (astat) {
+            p.tiles_m = (q.M + AS_BM - 1) / AS_BM;
+            int ranges = (int)((512 + mtiles - 1) / mtiles);
+            if (ranges > ntiles) ranges = ntiles;
+            if (ranges < 1) ranges = 1;
+            p.tiles_n = (ntiles + ranges - 1) / ranges;           // N tiles per workgroup
+            p.splitk = (ntiles + p.tiles_n - 1) / p.tiles_n;      // number of N ranges
+            p.splitk_is_one = 1;
+            tile += p.tiles_m * p.splitk;
+        } else {
+            p.tiles_m = (q.M + BM - 1) / BM;
+            p.tiles_n = ntiles;
+            p.splitk = q.splitk > 1 ? q.splitk : 1;
+            p.splitk_is_one = p.splitk == 1;
+            if (p.splitk > 1 && !((q.flags & BPM_GEMM_ATOMIC) && q.out_kind == BPM_OUT_F32)) return BPM_ERR_ARG;
+            tile += p.tiles_m * p.tiles_n * p.splitk;
+        }
     }
     g.total_tiles = tile;
     hipStream_t s = (hipStream_t)stream;
     double flops = 0;
     for (int i = 0; i < nprob; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * probs[i].K;
     BpmProfScope prof(BPM_K_GEMM_NT + variant, s, flops);
-    return dtype == BPM_BF16 ? launch<bf16_t>(variant, g, s) : launch<float>(variant, g, s);
+    return dtype == BPM_BF16 ? launch<bf16_t>(variant, astat, g, s) : launch<float>(variant, astat, g, s);
 }

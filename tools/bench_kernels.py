@@ -109,9 +109,12 @@ def main():
     gemm_case("NN dgrad fc1 (f32)", GEMM_NN, R, d, 4 * d, ld4, ld, d, G)
     gemm_case("NN dgrad out (heads)", GEMM_NN, R, d, d, ld, ld, 0, G, out_kind=OUT_HEADS)
     gemm_case("NN dgrad qkv (f32)", GEMM_NN, R, d, d, ld, ld, d, 3 * G)
-    gemm_case("TN wgrad ffn (atomic splitk8)", GEMM_TN, d, 4 * d, R, ld, ld4, 4 * d, G, flags=F_ATOMIC, splitk=8)
-    gemm_case("TN wgrad ffn (splitk1)", GEMM_TN, d, 4 * d, R, ld, ld4, 4 * d, G, flags=F_ATOMIC, splitk=1)
-    gemm_case("TN wgrad att (atomic splitk8)", GEMM_TN, d, d, R, ld, ld, d, 4 * G, flags=F_ATOMIC, splitk=8)
+    from bpmult_amd.ops import F_ACCUM
+    gemm_case("TN wgrad ffn 2G (accum)", GEMM_TN, d, 4 * d, R, ld, ld4, 4 * d, 2 * G, flags=F_ACCUM)
+    gemm_case("TN wgrad ffn 2G (atomic splitk2)", GEMM_TN, d, 4 * d, R, ld, ld4, 4 * d, 2 * G, flags=F_ATOMIC, splitk=2)
+    gemm_case("TN wgrad att 4G (accum)", GEMM_TN, d, d, R, ld, ld, d, 4 * G, flags=F_ACCUM)
+    gemm_case("TN wgrad att 4G (atomic splitk2)", GEMM_TN, d, d, R, ld, ld, d, 4 * G, flags=F_ATOMIC, splitk=2)
+    gemm_case("TN wgrad att 4G (atomic splitk4)", GEMM_TN, d, d, R, ld, ld, d, 4 * G, flags=F_ATOMIC, splitk=4)
 
     # ---- attention (causal T = S = N)
     aps = []
