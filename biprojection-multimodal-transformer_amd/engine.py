@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -218,6 +219,18 @@ def _splitk(tiles_total: int, k: int) -> int:
     return max(1, min(k // 512, 1024 // max(1, tiles_total), 16))
 
 
+SIDE, JOIN, MARK, WAIT = "side", "join", "mark", "wait"
+_SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 class EncoderGroupPlan:
     """Buffers + launch tables for G encoders x L layers at batch size B."""
 
@@ -257,13 +270,19 @@ class EncoderGroupPlan:
                                       ("lses", (B, H, e.T), torch.float32), ("xmid0", (R, d), torch.float32),
                                       ("xq", (R, self.ld), ct), ("st2m", (R,), torch.float32), ("st2r", (R,), torch.float32)):
                     b[nm] = [z(*shape, dt=dt) for _ in range(L)]
-                b["dks"], b["dvs"] = z(R, self.ld, dt=ct), z(R, self.ld, dt=ct)
             # backward temporaries (shared by all layers)
             b["dx"], b["dxn"] = z(R, d), z(R, d)
-            b["dy"], b["dh1"] = z(R, self.ld, dt=ct), z(R, self.ld4, dt=ct)
+            # Off-critical-path work (weight gradients, the key/value-side dgrad + LayerNorm backward) runs on a
+            # side stream up to two layers behind the main chain, so every operand it reads has its own buffer
+            # within a layer (dyf: FFN, dy: attention, dy0/dqs/dks/dvs: biprojection self-attention half) and is
+            # double-buffered by layer parity.
+            two = lambda *shape: [z(*shape, dt=ct), z(*shape, dt=ct)]
+            b["dy"], b["dyf"], b["dh1"] = two(R, self.ld), two(R, self.ld), two(R, self.ld4)
+            b["dq"], b["dk"], b["dv"] = two(R, self.ld), two(Rk, self.ld), two(Rk, self.ld)
+            if cfg.biprojection:
+                b["dy0"], b["dqs"], b["dks"], b["dvs"] = two(R, self.ld), two(R, self.ld), two(R, self.ld), two(R, self.ld)
             b["dao"] = z(B, H, e.T, self.dhp, dt=ct)
             b["delta"] = z(B, H, e.T)
-            b["dq"], b["dk"], b["dv"] = z(R, self.ld, dt=ct), z(Rk, self.ld, dt=ct), z(Rk, self.ld, dt=ct)
             b["dkn"], b["dvn"], b["dke"], b["dve"] = z(Rk, d), z(Rk, d), z(Rk, d), z(Rk, d)
             b["dxq"], b["dxk"], b["dxv"] = z(e.T, B, d), z(e.S, B, d), z(e.S, B, d)
             self.buf.append(b)
@@ -286,10 +305,11 @@ class EncoderGroupPlan:
         c, st, B, d, H = self.cfg, self.store, self.B, self.cfg.d, self.cfg.H
         ld, ld4, dh, dhp = self.ld, self.ld4, self.dh, self.dhp
         pr = (lambda p: p) if training else (lambda p: 0.0)
-        steps = []
+        steps, kv_steps = [], []
         A = ops.array
         for i in range(c.layers):
             ln, qkv, att, outp, ln2, fc1, fc2 = [], [], [], [], [], [], []
+            lnkv, kvp = [], []
             pre = dict(ln=[], qkv=[], att=[], outp=[], cast=[])      # biprojection self-attention half
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -326,11 +346,11 @@ class EncoderGroupPlan:
                     q_src, resid_src = b["xn"][i], x_in
                     gk, bk, gf, bf = g0, b0, g1, b1
                     stf = (b["st1m"][i], b["st1r"][i])
-                ln.append(ops.ln_problem(b["ke"], gk, bk, b["stkm"][i], b["stkr"][i], Rk, out=b["kn"][i], ldo=ld))
-                ln.append(ops.ln_problem(b["ve"], gk, bk, b["stvm"][i], b["stvr"][i], Rk, out=b["vn"][i], ldo=ld))
+                lnkv.append(ops.ln_problem(b["ke"], gk, bk, b["stkm"][i], b["stkr"][i], Rk, out=b["kn"][i], ldo=ld))
+                lnkv.append(ops.ln_problem(b["ve"], gk, bk, b["stvm"][i], b["stvr"][i], Rk, out=b["vn"][i], ldo=ld))
                 qkv.append(proj(q_src, R, 0, b["qh"][i], e.T))
-                qkv.append(proj(b["kn"][i], Rk, 1, b["kh"][i], e.S))
-                qkv.append(proj(b["vn"][i], Rk, 2, b["vh"][i], e.S))
+                kvp.append(proj(b["kn"][i], Rk, 1, b["kh"][i], e.S))
+                kvp.append(proj(b["vn"][i], Rk, 2, b["vh"][i], e.S))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
                                             self._mask_off(e.T, e.S), drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
                 outp.append(ops.gemm_problem(b["ao"][i], st.sptr(wo), b["xmid"][i], R, d, d, ld, ld, d,
@@ -349,8 +369,15 @@ class EncoderGroupPlan:
                           (ops.attn_fwd, self.dtype, A(AttnProblem, pre["att"])),
                           self._gemm(GEMM_NT, pre["outp"]),
                           (ops.rows_cast, self.dtype, A(CastProblem, pre["cast"]))]
-            steps += [(ops.ln_fwd, self.dtype, A(LnProblem, ln), d),
-                      self._gemm(GEMM_NT, qkv),
+            # K/V side of every layer depends only on the (embedded) key/value sources: the side stream runs it
+            # ahead of the query chain; the main stream waits for layer i's K/V heads just before attention i.
+            kv_steps += [(SIDE, (ops.ln_fwd, self.dtype, A(LnProblem, lnkv), d)),
+                         (SIDE, self._gemm(GEMM_NT, kvp)),
+                         (MARK, i)]
+            if ln:
+                steps.append((ops.ln_fwd, self.dtype, A(LnProblem, ln), d))
+            steps += [self._gemm(GEMM_NT, qkv),
+                      (WAIT, i),
                       (ops.attn_fwd, self.dtype, A(AttnProblem, att)),
                       self._gemm(GEMM_NT, outp),
                       (ops.ln_fwd, self.dtype, A(LnProblem, ln2), d),
@@ -360,23 +387,63 @@ class EncoderGroupPlan:
                               b["stf"][0], b["stf"][1], b["R"], out=b["out"], ldo=d, out_f32=True)
                for e, b in zip(self.encs, self.buf)]
         steps.append((ops.ln_fwd, self.dtype, A(LnProblem, fin), d))
-        return steps
+        return kv_steps + steps + [JOIN]
 
-    _SEEDED = (ops.gemm_grouped, ops.attn_fwd, ops.attn_bwd, ops.rows_cast)
+    @staticmethod
+    def _exec(s, seed: int) -> None:
+        fn = s[0]
+        if fn is ops.gemm_grouped:
+            fn(s[1], s[2], s[3], seed)
+        elif fn in (ops.attn_fwd, ops.attn_bwd, ops.rows_cast):
+            fn(s[1], s[2], seed)
+        elif fn is ops.ln_fwd:
+            fn(s[1], s[2], s[3])
+        elif fn is ops.ln_bwd:
+            fn(s[1], s[2])
+        else:
+            raise RuntimeError("unknown step")
 
     def _run(self, steps, seed: int) -> None:
+        """Launch a step table.  Plain steps go to the current ("main") stream.  (SIDE, step) goes to the side
+        stream, ordered behind everything the main stream has launched so far; (MARK, k) records an event on the
+        side stream; (WAIT, k) makes the main stream wait for mark k (no-op if it was never recorded); JOIN
+        makes the main stream wait for all side work.  With BPMULT_SIDE=0 everything runs on the main stream."""
+        if not _SIDE:
+            for s in steps:
+                if s is JOIN or s[0] is MARK or s[0] is WAIT:
+                    continue
+                self._exec(s[1] if s[0] is SIDE else s, seed)
+            return
+        main = torch.cuda.current_stream()
+        side = _side_stream(main.device)
+        marks: Dict[int, torch.cuda.Event] = {}
+        main_dirty, side_dirty = True, False
         for s in steps:
-            fn = s[0]
-            if fn is ops.gemm_grouped:
-                fn(s[1], s[2], s[3], seed)
-            elif fn in (ops.attn_fwd, ops.attn_bwd, ops.rows_cast):
-                fn(s[1], s[2], seed)
-            elif fn in (ops.ln_fwd,):
-                fn(s[1], s[2], s[3])
-            elif fn is ops.ln_bwd:
-                fn(s[1], s[2])
+            if s is JOIN:
+                if side_dirty:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    main.wait_event(ev)
+                    side_dirty = False
+            elif s[0] is SIDE:
+                if main_dirty:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    main_dirty = False
+                with torch.cuda.stream(side):
+                    self._exec(s[1], seed)
+                side_dirty = True
+            elif s[0] is MARK:
+                if side_dirty:
+                    marks[s[1]] = torch.cuda.Event()
+                    marks[s[1]].record(side)
+            elif s[0] is WAIT:
+                if s[1] in marks:
+                    main.wait_event(marks.pop(s[1]))
             else:
-                raise RuntimeError("unknown step")
+                self._exec(s, seed)
+                main_dirty = True
 
     def forward(self, xq: Sequence[torch.Tensor], xk: Sequence[torch.Tensor], xv: Sequence[torch.Tensor], seed: int,
                 training: bool) -> List[torch.Tensor]:
@@ -420,44 +487,47 @@ class EncoderGroupPlan:
                 lnK = 1 if c.biprojection else 0      # key/value LayerNorm index
                 stF = (b["st2m"][i], b["st2r"][i]) if c.biprojection else (b["st1m"][i], b["st1r"][i])
                 dx = b["dx"]
-                sk = lambda m, n: _splitk(((m + 127) // 128) * ((n + 63) // 64) * G * 2, R)
+                par = i & 1
+                dyf, dh1, dy, dq, dk, dv = (b[n][par] for n in ("dyf", "dh1", "dy", "dq", "dk", "dv"))
+                if c.biprojection:
+                    dy0, dqs, dks, dvs = (b[n][par] for n in ("dy0", "dqs", "dks", "dvs"))
                 # ---- FFN
-                cast2.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("fc2.bias"),
+                cast2.append(ops.cast_problem(dx, d, R, d, dst_ct=dyf, ldd=ld, colsum=GP("fc2.bias"),
                                               drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES2)))
-                wg_ffn.append(ops.gemm_problem(b["dy"], b["h1"][i], GP("fc2.weight"), d, 4 * d, R, ld, ld4, 4 * d,
+                wg_ffn.append(ops.gemm_problem(dyf, b["h1"][i], GP("fc2.weight"), d, 4 * d, R, ld, ld4, 4 * d,
                                                flags=F_ACCUM))
-                dg_fc2.append(ops.gemm_problem(b["dy"], st.sptr(w2), b["dh1"], R, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
+                dg_fc2.append(ops.gemm_problem(dyf, st.sptr(w2), dh1, R, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
                                                gate_scale=inv_relu, colsum=GP("fc1.bias"), out_kind=OUT_CT))
-                wg_ffn.append(ops.gemm_problem(b["dh1"], b["xn2"][i], GP("fc1.weight"), 4 * d, d, R, ld4, ld, d,
+                wg_ffn.append(ops.gemm_problem(dh1, b["xn2"][i], GP("fc1.weight"), 4 * d, d, R, ld4, ld, d,
                                                flags=F_ACCUM))
-                dg_fc1.append(ops.gemm_problem(b["dh1"], st.sptr(w1), b["dxn"], R, d, 4 * d, ld4, ld, d))
+                dg_fc1.append(ops.gemm_problem(dh1, st.sptr(w1), b["dxn"], R, d, 4 * d, ld4, ld, d))
                 lnf.append(ops.ln_problem(b["xmid"][i], P(f"layer_norms.{lnF}.weight"), None, stF[0], stF[1], R, dy=b["dxn"], ldy=d,
                                           add=dx, dx=dx, dgamma=GP(f"layer_norms.{lnF}.weight"), dbeta=GP(f"layer_norms.{lnF}.bias")))
                 # ---- (cross) attention block
-                cast1.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("self_attn.out_proj.bias"),
+                cast1.append(ops.cast_problem(dx, d, R, d, dst_ct=dy, ldd=ld, colsum=GP("self_attn.out_proj.bias"),
                                               drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES1)))
-                wg_att.append(ops.gemm_problem(b["dy"], b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
+                wg_att.append(ops.gemm_problem(dy, b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
                                                flags=F_ACCUM))
-                dg_out.append(ops.gemm_problem(b["dy"], st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                dg_out.append(ops.gemm_problem(dy, st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                heads=(B, H, e.T, dh, dhp)))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
-                                            self._mask_off(e.T, e.S), dO=b["dao"], delta=b["delta"], dQ=b["dq"], lddq=ld,
-                                            dK=b["dk"], lddk=ld, dV=b["dv"], lddv=ld, dq_scale=self.scale,
+                                            self._mask_off(e.T, e.S), dO=b["dao"], delta=b["delta"], dQ=dq, lddq=ld,
+                                            dK=dk, lddk=ld, dV=dv, lddv=ld, dq_scale=self.scale,
                                             drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
                 ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
-                for w, src, rows in ((0, b["dq"], R), (1, b["dk"], Rk), (2, b["dv"], Rk)):
+                for w, src, rows in ((0, dq, R), (1, dk, Rk), (2, dv, Rk)):
                     csum.append(ops.cast_problem(src, ld, rows, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
-                for w, dsrc, act, rows in ((0, b["dq"], q_src, R), (1, b["dk"], b["kn"][i], Rk), (2, b["dv"], b["vn"][i], Rk)):
+                for w, dsrc, act, rows in ((0, dq, q_src, R), (1, dk, b["kn"][i], Rk), (2, dv, b["vn"][i], Rk)):
                     wg_att.append(ops.gemm_problem(dsrc, act, st.gptr(ipw, w * d * d), d, d, rows, ld, ld, d, flags=F_ACCUM))
                 if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
-                    dg_q.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
+                    dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
                 else:
-                    dg_q.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
+                    dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
                     lnq.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R, dy=b["dxn"],
                                               ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias")))
-                dg_kv.append(ops.gemm_problem(b["dk"], st.sptr(ipw, d * ld), b["dkn"], Rk, d, d, ld, ld, d))
-                dg_kv.append(ops.gemm_problem(b["dv"], st.sptr(ipw, 2 * d * ld), b["dvn"], Rk, d, d, ld, ld, d))
+                dg_kv.append(ops.gemm_problem(dk, st.sptr(ipw, d * ld), b["dkn"], Rk, d, d, ld, ld, d))
+                dg_kv.append(ops.gemm_problem(dv, st.sptr(ipw, 2 * d * ld), b["dvn"], Rk, d, d, ld, ld, d))
                 gK, dgK, dbK = P(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.bias")
                 lnkv.append(ops.ln_problem(b["ke"], gK, None, b["stkm"][i], b["stkr"][i], Rk, dy=b["dkn"], ldy=d, add=b["dke"],
                                            dx=b["dke"], dgamma=dgK, dbeta=dbK))
@@ -465,52 +535,58 @@ class EncoderGroupPlan:
                                            dx=b["dve"], dgamma=dgK, dbeta=dbK))
                 if c.biprojection:
                     # ---- self-attention half (same attention parameters)
-                    s_cast0.append(ops.cast_problem(dx, d, R, d, dst_ct=b["dy"], ldd=ld, colsum=GP("self_attn.out_proj.bias"),
+                    s_cast0.append(ops.cast_problem(dx, d, R, d, dst_ct=dy0, ldd=ld, colsum=GP("self_attn.out_proj.bias"),
                                                     drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
-                    s_wg0.append(ops.gemm_problem(b["dy"], b["aos"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
+                    s_wg0.append(ops.gemm_problem(dy0, b["aos"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
                                                   flags=F_ACCUM))
-                    s_dgout0.append(ops.gemm_problem(b["dy"], st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                    s_dgout0.append(ops.gemm_problem(dy0, st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                      heads=(B, H, e.T, dh, dhp)))
                     s_att0.append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H, e.T, e.T,
-                                                   dh, dhp, self._mask_off(e.T, e.T), dO=b["dao"], delta=b["delta"], dQ=b["dq"],
-                                                   lddq=ld, dK=b["dks"], lddk=ld, dV=b["dvs"], lddv=ld, dq_scale=self.scale,
+                                                   dh, dhp, self._mask_off(e.T, e.T), dO=b["dao"], delta=b["delta"], dQ=dqs,
+                                                   lddq=ld, dK=dks, lddk=ld, dV=dvs, lddv=ld, dq_scale=self.scale,
                                                    drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
-                    for w, src in ((0, b["dq"]), (1, b["dks"]), (2, b["dvs"])):
+                    for w, src in ((0, dqs), (1, dks), (2, dvs)):
                         s_csum0.append(ops.cast_problem(src, ld, R, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
                         s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, ld, ld, d, flags=F_ACCUM))
                     # d(xn) = dq Wq + dk Wk + dv Wv: three launches (plain store, then two +=) -- one owner per
                     # output tile in each launch, no atomics (per-lane-scattered float atomics run ~17x below store rate)
-                    s_dg0a.append(ops.gemm_problem(b["dq"], st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
-                    s_dg0b.append(ops.gemm_problem(b["dks"], st.sptr(ipw, d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
-                    s_dg0c.append(ops.gemm_problem(b["dvs"], st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
+                    s_dg0a.append(ops.gemm_problem(dqs, st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
+                    s_dg0b.append(ops.gemm_problem(dks, st.sptr(ipw, d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
+                    s_dg0c.append(ops.gemm_problem(dvs, st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
                     s_ln0.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R,
                                                 dy=b["dxn"], ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"),
                                                 dbeta=GP("layer_norms.0.bias")))
-            steps += [(ops.rows_cast, self.dtype, A(CastProblem, cast2)),
+            # Side stream (SIDE): weight gradients and the key/value-side dgrad + LayerNorm backward -- nothing on
+            # the backward critical path consumes them.  Temporaries are double-buffered by layer parity, so the
+            # main chain only waits (WAIT) for the side work of two layers ago before overwriting them.
+            steps += [(WAIT, i + 2),
+                      (ops.rows_cast, self.dtype, A(CastProblem, cast2)),
                       self._gemm(GEMM_NN, dg_fc2),
-                      self._gemm(GEMM_TN, wg_ffn),
+                      (SIDE, self._gemm(GEMM_TN, wg_ffn)),
                       self._gemm(GEMM_NN, dg_fc1),
                       (ops.ln_bwd, A(LnProblem, lnf), d),
                       (ops.rows_cast, self.dtype, A(CastProblem, cast1)),
                       self._gemm(GEMM_NN, dg_out),
                       (ops.attn_bwd, self.dtype, A(AttnProblem, att)),
                       (ops.rows_cast, self.dtype, A(CastProblem, csum)),
-                      self._gemm(GEMM_TN, wg_att),
-                      self._gemm(GEMM_NN, dg_q + dg_kv)]
+                      (SIDE, self._gemm(GEMM_TN, wg_att)),
+                      (SIDE, self._gemm(GEMM_NN, dg_kv)),
+                      (SIDE, (ops.ln_bwd, A(LnProblem, lnkv), d)),
+                      self._gemm(GEMM_NN, dg_q)]
             if lnq:
-                steps.append((ops.ln_bwd, A(LnProblem, lnq + lnkv), d))
-            else:
-                steps.append((ops.ln_bwd, A(LnProblem, lnkv), d))
+                steps.append((ops.ln_bwd, A(LnProblem, lnq), d))
             if c.biprojection:
                 steps += [(ops.rows_cast, self.dtype, A(CastProblem, s_cast0)),
                           self._gemm(GEMM_NN, s_dgout0),
                           (ops.attn_bwd, self.dtype, A(AttnProblem, s_att0)),
                           (ops.rows_cast, self.dtype, A(CastProblem, s_csum0)),
-                          self._gemm(GEMM_TN, s_wg0),
+                          (SIDE, self._gemm(GEMM_TN, s_wg0)),
                           self._gemm(GEMM_NN, s_dg0a),
                           self._gemm(GEMM_NN, s_dg0b),
                           self._gemm(GEMM_NN, s_dg0c),
                           (ops.ln_bwd, A(LnProblem, s_ln0), d)]
+            steps.append((MARK, i))
+        steps.append(JOIN)
         return steps
 
     def backward(self, douts: Sequence[Optional[torch.Tensor]]):
