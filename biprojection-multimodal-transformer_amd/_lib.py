@@ -91,7 +91,9 @@ class LnProblem(C.Structure):
                 ("out", C.c_void_p), ("ldo", C.c_int), ("out_f32", C.c_int),
                 ("mean", C.c_void_p), ("rstd", C.c_void_p), ("R", C.c_int),
                 ("dy", C.c_void_p), ("ldy", C.c_int), ("add", C.c_void_p), ("dx", C.c_void_p),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("cast", C.c_void_p), ("ldc", C.c_int), ("cast_colsum", C.c_void_p),
+                ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
 
 
 class CastProblem(C.Structure):
@@ -124,7 +126,7 @@ SIGNATURES = {
     "bpm_embed_pos_fwd": [C.POINTER(EmbedProblem), _I, _P, _I, _I, _F, _U64, _P],
     "bpm_embed_pos_bwd": [C.POINTER(EmbedProblem), _I, _I, _F, _U64, _P],
     "bpm_ln_fwd": [_I, C.POINTER(LnProblem), _I, _I, _F, _P],
-    "bpm_ln_bwd": [C.POINTER(LnProblem), _I, _I, _P],
+    "bpm_ln_bwd": [_I, C.POINTER(LnProblem), _I, _I, _U64, _P],
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],

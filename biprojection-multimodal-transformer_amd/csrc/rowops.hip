@@ -149,6 +149,7 @@ struct LnP {
     const float* x; const float* gamma; const float* beta; void* out; int ldo; int out_f32;
     float* mean; float* rstd; int R;
     const float* dy; int ldy; const float* add; float* dx; float* dgamma; float* dbeta;
+    void* cast; int ldc; float* csum; DropCfg drop;
 };
 
 template <typename CT, int NE>
@@ -193,34 +194,37 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const Grp<LnP> grp, int d, f
 
 // dx = add + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // dgamma += sum_rows dy * xhat,  dbeta += sum_rows dy   (atomics, one per column per block)
-template <int NE>
+// optional: cast[row, c] = CT(dx * dropout_mult(row*d + c)) (pad columns zeroed), csum += its column sums
+template <typename CT, int NE>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const Grp<LnP> grp, int d) {
-    __shared__ float red[2][NT / 64][512];   // 512 columns per pass
+    __shared__ float red[3][NT / 64][512];   // 512 columns per pass
     unsigned bid = blockIdx.x, nblk;
     const LnP& P = pick(grp, bid, nblk);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wpb = NT / 64;
-    float ag[NE], ab[NE];
+    const bool fused = P.cast != nullptr;          // uniform per block
+    float ag[NE], ab[NE], ac[NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
+    for (int e = 0; e < NE; ++e) { ag[e] = 0.f; ab[e] = 0.f; ac[e] = 0.f; }
     for (int row = bid * wpb + wv; row < P.R; row += nblk * wpb) {
         const float mu = P.mean[row], rs = P.rstd[row];
         const float* xr = P.x + (size_t)row * d;
         const float* gr = P.dy + (size_t)row * P.ldy;
-        float xh[NE], gg[NE];
+        float xh[NE], gg[NE], av[NE];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int c = lane + 64 * e;
             if (c < d) {
                 const float dyv = gr[c];
+                av[e] = P.add ? P.add[(size_t)row * d + c] : 0.f;
                 xh[e] = (xr[c] - mu) * rs;
                 gg[e] = dyv * P.gamma[c];
                 ag[e] += dyv * xh[e];
                 ab[e] += dyv;
                 s1 += gg[e];
                 s2 += gg[e] * xh[e];
-            } else { xh[e] = 0.f; gg[e] = 0.f; }
+            } else { xh[e] = 0.f; gg[e] = 0.f; av[e] = 0.f; }
         }
         s1 = wave_sum(s1) / d;
         s2 = wave_sum(s2) / d;
@@ -228,30 +232,40 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const Grp<LnP> grp, int d) {
         for (int e = 0; e < NE; ++e) {
             const int c = lane + 64 * e;
             if (c < d) {
-                const float v = rs * (gg[e] - s1 - xh[e] * s2);
-                const size_t i = (size_t)row * d + c;
-                P.dx[i] = P.add ? P.add[i] + v : v;
+                const float v = av[e] + rs * (gg[e] - s1 - xh[e] * s2);
+                P.dx[(size_t)row * d + c] = v;
+                if (fused) {
+                    const float m = v * bpm_drop_mult(P.drop, (uint32_t)row * (uint32_t)d + (uint32_t)c);
+                    put<CT>(P.cast, (size_t)row * P.ldc + c, m);
+                    ac[e] += m;
+                }
+            } else if (fused && c < P.ldc) {
+                put<CT>(P.cast, (size_t)row * P.ldc + c, 0.f);
             }
         }
     }
-    if (!P.dgamma) return;     // uniform per block
+    const bool want_g = P.dgamma != nullptr, want_c = fused && P.csum != nullptr;
+    if (!want_g && !want_c) return;     // uniform per block
 #pragma unroll
     for (int e0 = 0; e0 < NE; e0 += 8) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            red[0][wv][lane + 64 * e] = (e0 + e < NE) ? ag[(e0 + e < NE) ? e0 + e : 0] : 0.f;
-            red[1][wv][lane + 64 * e] = (e0 + e < NE) ? ab[(e0 + e < NE) ? e0 + e : 0] : 0.f;
+            const bool in = e0 + e < NE;
+            const int ei = in ? e0 + e : 0;
+            red[0][wv][lane + 64 * e] = in ? ag[ei] : 0.f;
+            red[1][wv][lane + 64 * e] = in ? ab[ei] : 0.f;
+            red[2][wv][lane + 64 * e] = in ? ac[ei] : 0.f;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < 512; i += NT) {
             const int c = e0 * 64 + i;
             if (c < d) {
-                float sg = 0.f, sb = 0.f;
+                float sg = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
-                for (int w = 0; w < NT / 64; ++w) { sg += red[0][w][i]; sb += red[1][w][i]; }
-                atomicAdd(P.dgamma + c, sg);
-                atomicAdd(P.dbeta + c, sb);
+                for (int w = 0; w < NT / 64; ++w) { sg += red[0][w][i]; sb += red[1][w][i]; sc += red[2][w][i]; }
+                if (want_g) { atomicAdd(P.dgamma + c, sg); atomicAdd(P.dbeta + c, sb); }
+                if (want_c) atomicAdd(P.csum + c, sc);
             }
         }
     }
@@ -433,7 +447,7 @@ extern "C" int bpm_embed_pos_bwd(const bpm_embed_problem* q, int n, int d, float
     return 0;
 }
 
-static int fill_ln(Grp<LnP>& g, const bpm_ln_problem* q, int n, int d, bool bwd, int* span) {
+static int fill_ln(Grp<LnP>& g, const bpm_ln_problem* q, int n, int d, bool bwd, int* span, uint64_t seed = 0) {
     if (!q || n < 1 || n > BPM_MAX_GROUP || d < 1 || d > 64 * MAXE) return BPM_ERR_ARG;
     g.n = n; g.blk0[0] = 0;
     *span = d;
@@ -443,6 +457,8 @@ static int fill_ln(Grp<LnP>& g, const bpm_ln_problem* q, int n, int d, bool bwd,
         if (!s.x || !s.gamma || !s.mean || !s.rstd || s.R < 1) return BPM_ERR_ARG;
         if (bwd) {
             if (!s.dy || !s.dx || s.ldy < d || ((s.dgamma == nullptr) != (s.dbeta == nullptr))) return BPM_ERR_ARG;
+            if (s.cast && (s.ldc < d || s.ldc > 64 * ((d + 63) / 64))) return BPM_ERR_ARG;
+            if (!s.cast && s.cast_colsum) return BPM_ERR_ARG;
         } else {
             if (!s.beta || !s.out || s.ldo < d || s.ldo > 64 * MAXE) return BPM_ERR_ARG;
             if (!s.out_f32 && s.ldo > *span) *span = s.ldo;
@@ -450,6 +466,8 @@ static int fill_ln(Grp<LnP>& g, const bpm_ln_problem* q, int n, int d, bool bwd,
         p.x = s.x; p.gamma = s.gamma; p.beta = s.beta; p.out = s.out; p.ldo = s.ldo; p.out_f32 = s.out_f32;
         p.mean = s.mean; p.rstd = s.rstd; p.R = s.R;
         p.dy = s.dy; p.ldy = s.ldy; p.add = s.add; p.dx = s.dx; p.dgamma = s.dgamma; p.dbeta = s.dbeta;
+        p.cast = bwd ? s.cast : nullptr; p.ldc = s.ldc; p.csum = s.cast_colsum;
+        p.drop = make_drop(bwd && s.cast ? s.drop_p : 0.f, seed, s.drop_site);
         g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)s.R, 4, bwd ? 256 : 4096);
     }
     return 0;
@@ -473,16 +491,19 @@ extern "C" int bpm_ln_fwd(int dtype, const bpm_ln_problem* q, int n, int d, floa
     return BPM_ERR_ARG;
 }
 
-extern "C" int bpm_ln_bwd(const bpm_ln_problem* q, int n, int d, void* stream) {
+extern "C" int bpm_ln_bwd(int dtype, const bpm_ln_problem* q, int n, int d, uint64_t seed, void* stream) {
+    if (dtype != BPM_F32 && dtype != BPM_BF16) return BPM_ERR_ARG;
     Grp<LnP> g;
     int span;
-    int rc = fill_ln(g, q, n, d, true, &span);
+    int rc = fill_ln(g, q, n, d, true, &span, seed);
     if (rc) return rc;
-#define BPM_LN_BWD(NE)                                                                                        \
-    if (d <= 64 * NE) {                                                                                       \
-        hipLaunchKernelGGL(ln_bwd_kernel<NE>, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, d);       \
-        BPM_CHECK_LAUNCH();                                                                                   \
-        return 0;                                                                                             \
+    hipStream_t s = (hipStream_t)stream;
+#define BPM_LN_BWD(NE)                                                                                               \
+    if (d <= 64 * NE) {                                                                                              \
+        if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NE>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<float, NE>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d);                   \
+        BPM_CHECK_LAUNCH();                                                                                          \
+        return 0;                                                                                                    \
     }
     BPM_LN_BWD(1) BPM_LN_BWD(2) BPM_LN_BWD(5) BPM_LN_BWD(8) BPM_LN_BWD(12) BPM_LN_BWD(16) BPM_LN_BWD(24) BPM_LN_BWD(32)
 #undef BPM_LN_BWD

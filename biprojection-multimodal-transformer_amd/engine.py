@@ -277,7 +277,9 @@ class EncoderGroupPlan:
             # within a layer (dyf: FFN, dy: attention, dy0/dqs/dks/dvs: biprojection self-attention half) and is
             # double-buffered by layer parity.
             two = lambda *shape: [z(*shape, dt=ct), z(*shape, dt=ct)]
-            b["dy"], b["dyf"], b["dh1"] = two(R, self.ld), two(R, self.ld), two(R, self.ld4)
+            b["dy"], b["dh1"] = two(R, self.ld), two(R, self.ld4)
+            # dyf[i % 3]: written one layer early (fused into the LayerNorm backward that produces dx)
+            b["dyf"] = [z(R, self.ld, dt=ct) for _ in range(3)]
             b["dq"], b["dk"], b["dv"] = two(R, self.ld), two(Rk, self.ld), two(Rk, self.ld)
             if cfg.biprojection:
                 b["dy0"], b["dqs"], b["dks"], b["dvs"] = two(R, self.ld), two(R, self.ld), two(R, self.ld), two(R, self.ld)
@@ -389,8 +391,7 @@ class EncoderGroupPlan:
         steps.append((ops.ln_fwd, self.dtype, A(LnProblem, fin), d))
         return kv_steps + steps + [JOIN]
 
-    @staticmethod
-    def _exec(s, seed: int) -> None:
+    def _exec(self, s, seed: int) -> None:
         fn = s[0]
         if fn is ops.gemm_grouped:
             fn(s[1], s[2], s[3], seed)
@@ -399,7 +400,7 @@ class EncoderGroupPlan:
         elif fn is ops.ln_fwd:
             fn(s[1], s[2], s[3])
         elif fn is ops.ln_bwd:
-            fn(s[1], s[2])
+            fn(s[1], s[2], self.dtype, seed)
         else:
             raise RuntimeError("unknown step")
 
@@ -474,8 +475,8 @@ class EncoderGroupPlan:
         steps = []
         inv_relu = 1.0 / (1.0 - pr(c.relu_dropout))
         for i in reversed(range(c.layers)):
-            cast2, wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], [], []
-            cast1, wg_att, dg_out, att, csum, dg_q, dg_kv, lnq, lnkv = [], [], [], [], [], [], [], [], []
+            wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], []
+            wg_att, dg_out, att, csum, dg_q, dg_kv, lnq, lnkv = [], [], [], [], [], [], [], []
             s_cast0, s_dgout0, s_att0, s_csum0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], [], []
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -488,12 +489,15 @@ class EncoderGroupPlan:
                 stF = (b["st2m"][i], b["st2r"][i]) if c.biprojection else (b["st1m"][i], b["st1r"][i])
                 dx = b["dx"]
                 par = i & 1
-                dyf, dh1, dy, dq, dk, dv = (b[n][par] for n in ("dyf", "dh1", "dy", "dq", "dk", "dv"))
+                dh1, dy, dq, dk, dv = (b[n][par] for n in ("dh1", "dy", "dq", "dk", "dv"))
+                dyf = b["dyf"][i % 3]
+                # hand-off to the next layer down (i-1): its FFN-output gradient dyf = dropmask(dx) and fc2.bias
+                # gradient are produced by whichever LayerNorm backward finishes this layer's dx
+                nxt = {} if i == 0 else dict(cast=b["dyf"][(i - 1) % 3], ldc=ld, cast_colsum=st.gptr(self._pn(e, i - 1, "fc2.bias")),
+                                             drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i - 1, S_RES2))
                 if c.biprojection:
                     dy0, dqs, dks, dvs = (b[n][par] for n in ("dy0", "dqs", "dks", "dvs"))
                 # ---- FFN
-                cast2.append(ops.cast_problem(dx, d, R, d, dst_ct=dyf, ldd=ld, colsum=GP("fc2.bias"),
-                                              drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES2)))
                 wg_ffn.append(ops.gemm_problem(dyf, b["h1"][i], GP("fc2.weight"), d, 4 * d, R, ld, ld4, 4 * d,
                                                flags=F_ACCUM))
                 dg_fc2.append(ops.gemm_problem(dyf, st.sptr(w2), dh1, R, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
@@ -502,10 +506,10 @@ class EncoderGroupPlan:
                                                flags=F_ACCUM))
                 dg_fc1.append(ops.gemm_problem(dh1, st.sptr(w1), b["dxn"], R, d, 4 * d, ld4, ld, d))
                 lnf.append(ops.ln_problem(b["xmid"][i], P(f"layer_norms.{lnF}.weight"), None, stF[0], stF[1], R, dy=b["dxn"], ldy=d,
-                                          add=dx, dx=dx, dgamma=GP(f"layer_norms.{lnF}.weight"), dbeta=GP(f"layer_norms.{lnF}.bias")))
+                                          add=dx, dx=dx, dgamma=GP(f"layer_norms.{lnF}.weight"), dbeta=GP(f"layer_norms.{lnF}.bias"),
+                                          cast=dy, ldc=ld, cast_colsum=GP("self_attn.out_proj.bias"), drop_p=pr(c.res_dropout),
+                                          drop_site=site(e.enc_id, i, S_RES1)))
                 # ---- (cross) attention block
-                cast1.append(ops.cast_problem(dx, d, R, d, dst_ct=dy, ldd=ld, colsum=GP("self_attn.out_proj.bias"),
-                                              drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES1)))
                 wg_att.append(ops.gemm_problem(dy, b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
                                                flags=F_ACCUM))
                 dg_out.append(ops.gemm_problem(dy, st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
@@ -525,7 +529,8 @@ class EncoderGroupPlan:
                 else:
                     dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
                     lnq.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R, dy=b["dxn"],
-                                              ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias")))
+                                              ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias"),
+                                              **nxt))
                 dg_kv.append(ops.gemm_problem(dk, st.sptr(ipw, d * ld), b["dkn"], Rk, d, d, ld, ld, d))
                 dg_kv.append(ops.gemm_problem(dv, st.sptr(ipw, 2 * d * ld), b["dvn"], Rk, d, d, ld, ld, d))
                 gK, dgK, dbK = P(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.bias")
@@ -555,20 +560,18 @@ class EncoderGroupPlan:
                     s_dg0c.append(ops.gemm_problem(dvs, st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
                     s_ln0.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R,
                                                 dy=b["dxn"], ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"),
-                                                dbeta=GP("layer_norms.0.bias")))
+                                                dbeta=GP("layer_norms.0.bias"), **nxt))
             # Side stream (SIDE): weight gradients and the key/value-side dgrad + LayerNorm backward -- nothing on
             # the backward critical path consumes them.  Temporaries are double-buffered by layer parity, so the
             # main chain only waits (WAIT) for the side work of two layers ago before overwriting them.
             steps += [(WAIT, i + 2),
-                      (ops.rows_cast, self.dtype, A(CastProblem, cast2)),
                       self._gemm(GEMM_NN, dg_fc2),
                       (SIDE, self._gemm(GEMM_TN, wg_ffn)),
                       self._gemm(GEMM_NN, dg_fc1),
                       (ops.ln_bwd, A(LnProblem, lnf), d),
-                      (ops.rows_cast, self.dtype, A(CastProblem, cast1)),
                       self._gemm(GEMM_NN, dg_out),
                       (ops.attn_bwd, self.dtype, A(AttnProblem, att)),
-                      (ops.rows_cast, self.dtype, A(CastProblem, csum)),
+                      (SIDE, (ops.rows_cast, self.dtype, A(CastProblem, csum))),
                       (SIDE, self._gemm(GEMM_TN, wg_att)),
                       (SIDE, self._gemm(GEMM_NN, dg_kv)),
                       (SIDE, (ops.ln_bwd, A(LnProblem, lnkv), d)),
@@ -579,7 +582,7 @@ class EncoderGroupPlan:
                 steps += [(ops.rows_cast, self.dtype, A(CastProblem, s_cast0)),
                           self._gemm(GEMM_NN, s_dgout0),
                           (ops.attn_bwd, self.dtype, A(AttnProblem, s_att0)),
-                          (ops.rows_cast, self.dtype, A(CastProblem, s_csum0)),
+                          (SIDE, (ops.rows_cast, self.dtype, A(CastProblem, s_csum0))),
                           (SIDE, self._gemm(GEMM_TN, s_wg0)),
                           self._gemm(GEMM_NN, s_dg0a),
                           self._gemm(GEMM_NN, s_dg0b),
@@ -596,19 +599,23 @@ class EncoderGroupPlan:
         seed, training = self._last
         c, st, B, d = self.cfg, self.store, self.B, self.cfg.d
         fin, keep = [], []
+        top = c.layers - 1
         for e, b, g in zip(self.encs, self.buf, douts):
             b["dke"].zero_()
             b["dve"].zero_()
             if g is None:
                 b["dx"].zero_()
+                b["dyf"][top % 3].zero_()
                 continue
             g = g.contiguous()
             keep.append(g)
             fin.append(ops.ln_problem(b["x"][c.layers], st.p(e.prefix + "layer_norm.weight"), None, b["stf"][0], b["stf"][1], b["R"],
                                       dy=g, ldy=d, dx=b["dx"], dgamma=st.gptr(e.prefix + "layer_norm.weight"),
-                                      dbeta=st.gptr(e.prefix + "layer_norm.bias")))
+                                      dbeta=st.gptr(e.prefix + "layer_norm.bias"),
+                                      cast=b["dyf"][top % 3], ldc=self.ld, cast_colsum=st.gptr(self._pn(e, top, "fc2.bias")),
+                                      drop_p=c.res_dropout if training else 0.0, drop_site=site(e.enc_id, top, S_RES2)))
         if fin:
-            ops.ln_bwd(fin, d)
+            ops.ln_bwd(fin, d, self.dtype, seed)
         self._run(self._bwd[training], seed)
         p = c.embed_dropout if training else 0.0
         emb = []

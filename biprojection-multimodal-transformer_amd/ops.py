@@ -168,13 +168,16 @@ def embed_pos_bwd(probs, d, scale, seed=0) -> None:
 
 
 def ln_problem(x, gamma, beta, mean, rstd, R, *, out=None, ldo=0, out_f32=False, dy=None, ldy=0, add=None, dx=None,
-               dgamma=None, dbeta=None) -> LnProblem:
+               dgamma=None, dbeta=None, cast=None, ldc=0, cast_colsum=None, drop_p=0.0, drop_site=0) -> LnProblem:
     p = LnProblem()
     p.x, p.gamma, p.beta = _f32(x, "ln.x"), _f32(gamma, "ln.gamma"), _f32(beta, "ln.beta")
     p.out, p.ldo, p.out_f32 = _p(out), ldo, int(out_f32)
     p.mean, p.rstd, p.R = _f32(mean, "ln.mean"), _f32(rstd, "ln.rstd"), R
     p.dy, p.ldy, p.add, p.dx = _f32(dy, "ln.dy"), ldy, _f32(add, "ln.add"), _f32(dx, "ln.dx")
     p.dgamma, p.dbeta = _f32(dgamma, "ln.dgamma"), _f32(dbeta, "ln.dbeta")
+    p.cast, p.ldc = _p(cast), ldc
+    p.cast_colsum = cast_colsum if isinstance(cast_colsum, int) else _f32(cast_colsum, "ln.cast_colsum")
+    p.drop_p, p.drop_site = drop_p, drop_site
     return p
 
 
@@ -184,10 +187,12 @@ def ln_fwd(dtype, probs, d, eps=1e-5) -> None:
         _lib.check(_lib.lib().bpm_ln_fwd(dtype, sub, k, d, eps, _stream()), "bpm_ln_fwd")
 
 
-def ln_bwd(probs, d) -> None:
+def ln_bwd(probs, d, dtype=None, seed=0) -> None:
+    """dtype / seed only matter for problems with a fused `cast` output."""
     arr = _as_array(LnProblem, probs)
+    dt = BPM_F32 if dtype is None else dtype
     for sub, k in _chunks(arr, LnProblem, None):
-        _lib.check(_lib.lib().bpm_ln_bwd(sub, k, d, _stream()), "bpm_ln_bwd")
+        _lib.check(_lib.lib().bpm_ln_bwd(dt, sub, k, d, seed, _stream()), "bpm_ln_bwd")
 
 
 def cast_problem(a, lda, R, Cn, *, a_is_ct=False, b=None, ldb=0, dst_ct=None, ldd=0, ct_cols=0, dst_f32=None, ldf=0, colsum=None,

@@ -159,16 +159,22 @@ int bpm_embed_pos_bwd(const bpm_embed_problem* probs, int n, int d, float scale,
 /* LayerNorm (nn.LayerNorm(d), eps inside sqrt; transformer.py:91,153,167-172,
  * 183-185,227-229).  x fp32 [R,d].  Forward writes CT [R, ldo] with zero pad
  * columns, or plain fp32 [R, ldo] when out_f32; saves mean / rstd [R].
- * Backward: dx = add + dLN(dy); dgamma/dbeta += by atomics (both or neither). */
+ * Backward: dx = add + dLN(dy); dgamma/dbeta += by atomics (both or neither).
+ * Optional fused hand-off to the next backward GEMM (what bpm_rows_cast would
+ * do with a = dx): cast = CT [R, ldc] copy of dx * dropout_mult(r*d + c) with
+ * zero pad columns, cast_colsum[d] += its column sums (the bias gradient of
+ * the linear whose output this residual branch was; transformer.py:174-175,
+ * 189-190). */
 typedef struct bpm_ln_problem {
     const float* x; const float* gamma; const float* beta;
     void* out; int ldo; int out_f32;
     float* mean; float* rstd;
     int R;
     const float* dy; int ldy; const float* add; float* dx; float* dgamma; float* dbeta;   /* backward */
+    void* cast; int ldc; float* cast_colsum; float drop_p; uint32_t drop_site;           /* backward, optional */
 } bpm_ln_problem;
 int bpm_ln_fwd(int dtype, const bpm_ln_problem* probs, int n, int d, float eps, void* stream);
-int bpm_ln_bwd(const bpm_ln_problem* probs, int n, int d, void* stream);
+int bpm_ln_bwd(int dtype, const bpm_ln_problem* probs, int n, int d, uint64_t seed, void* stream);
 
 /* y = (a [+ b]) * dropout_mult(r*C + c); a is fp32 or (a_is_ct) CT.  Outputs,
  * each optional: CT copy [R, ldd] (pad zeroed), fp32 copy, column sums (+= by

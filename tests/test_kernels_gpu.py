@@ -275,6 +275,17 @@ def test_layernorm(dtype, R, d):
     close(dx2, x.grad, 1e-4, "ln dx (no add, no param grads)")
     close(dgam, gamma.grad, 1e-4, "ln dgamma")
     close(dbet, beta.grad, 1e-4, "ln dbeta")
+    # fused hand-off: CT copy of dropmask(dx) with zero pad + its column sums (== bpm_rows_cast on dx)
+    dx3 = torch.empty(R, d, device=DEV)
+    cast = torch.full((R, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
+    cs = torch.ones(d, device=DEV)
+    ops.ln_bwd([ops.ln_problem(xd, gd, None, mean, rstd, R, dy=dyd, ldy=d, add=add, dx=dx3, cast=cast, ldc=ld, cast_colsum=cs,
+                               drop_p=0.2, drop_site=9)], d, dtype, 1234)
+    assert torch.equal(dx3, dx)
+    want = dx.cpu() * drop_mult((R, d), 0.2, 1234, 9)
+    close(cast[:, :d].float(), want, 1e-6 if dtype == BPM_F32 else 1e-2, "ln fused cast")
+    assert (cast[:, d:].float() == 0).all()
+    close(cs, 1 + want.sum(0), 1e-4, "ln fused colsum")
 
 
 @pytest.mark.parametrize("dtype", DT)
