@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
     char* kimg = smem;
     char* vimg = smem + KT * C::STRIDE;
 
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
     const int bh = bid / P.nblk, qb = bid % P.nblk;
     const int b = bh / P.H, h = bh % P.H;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
     char* kimg = smem;
     char* vimg = smem + KT * C::STRIDE;
 
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
     const int bh = bid / P.nblk, qb = bid % P.nblk;
     const int b = bh / P.H, h = bh % P.H;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
     float* s_lse = (float*)(smem + 2 * QT * C::STRIDE);      // -lse * log2(e)
     float* s_del = s_lse + QT;
 
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
     const int bh = bid / P.nblk, kb = bid % P.nblk;
     const int b = bh / P.H, h = bh % P.H;

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiled_kernel(const Group grp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const Prob& P = pick_problem(grp, bid);
     const int tiles = P.tiles_m * P.tiles_n;
     const int split = bid / tiles;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_astat_kernel(const Group grp) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const Prob& P = pick_problem(grp, bid);
     const int mt = bid / P.splitk, ns = bid % P.splitk;
     const int m0 = mt * AS_BM + wave * 32;
