@@ -42,6 +42,7 @@
 // atomics only for split-K), CT row-major (pad columns zeroed) or CT
 // head-major [B,H,T,dhp] (attention operand layout).
 #include <cstdlib>
+#include <type_traits>
 
 #include "bpm_common.h"
 #include "bpm_prof.h"
@@ -49,14 +50,31 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 64, WM = 2, WN = 2;
+#ifndef BPM_BM
+#define BPM_BM 128
+#define BPM_BN 64
+#define BPM_WM 2
+#define BPM_WN 2
+#endif
+constexpr int BM = BPM_BM, BN = BPM_BN, WM = BPM_WM, WN = BPM_WN;
 constexpr int NTHREADS = 64 * WM * WN;
 constexpr int TM = BM / WM / 16;          // 4 MFMA tiles along m per wave
 constexpr int TN = BN / WN / 16;          // 2 along n
 // 64-byte k-steps per LDS stage of the tiled kernel.  Measured on MI355X at the model's shapes: the
 // forward / dgrad GEMMs with short k loops are latency bound and the smaller stage (12 KB, 5 workgroups
 // per CU) wins by 25-50 %; the weight-gradient GEMM (K = T*B rows) prefers the longer stage.
-constexpr int KS_FWD = 1, KS_WGRAD = 2;
+// waves per SIMD the tiled kernel is compiled for (register budget 512 / BPM_TILED_MINW per lane): 4 keeps the
+// two-phase epilogue's operand registers without spilling; 5 spills
+#ifndef BPM_TILED_MINW
+#define BPM_TILED_MINW 4
+#endif
+#ifndef BPM_KS_FWD
+#define BPM_KS_FWD 1
+#endif
+#ifndef BPM_KS_WGRAD
+#define BPM_KS_WGRAD 2
+#endif
+constexpr int KS_FWD = BPM_KS_FWD, KS_WGRAD = BPM_KS_WGRAD;
 // A-stationary kernel: up to 10 k-steps (640 bytes of k per row) held in registers
 constexpr int AS_KS = 10;
 constexpr int AS_BM = 128;                // 4 waves x 32 rows
@@ -226,7 +244,7 @@ BPM_DEV void flush_colsum(const Prob& P, float (&csum)[4], int nb, int r) {
 BPM_DEV bool epi_fast_ok(const Prob& P) {
     const uintptr_t al = (uintptr_t)P.bias_n | (uintptr_t)P.resid | (uintptr_t)P.C | (uintptr_t)P.gate;
     return (P.N & 3) == 0 && (al & 15) == 0 && ((P.ldr | P.ldc | P.ldg) & 3) == 0 && !P.bias_m &&
-           !(P.flags & BPM_GEMM_ATOMIC) && P.splitk_is_one;
+           !(P.flags & BPM_GEMM_ATOMIC) && P.splitk_is_one && !(P.resid && (P.flags & BPM_GEMM_ACCUM));
 }
 
 struct EpiRow {            // per output row m: everything that does not depend on the column
@@ -248,51 +266,83 @@ BPM_DEV EpiRow epi_row(const Prob& P, int m) {
     return e;
 }
 
-template <typename CT>
-BPM_DEV void epilogue_fast(const Prob& P, const EpiRow& e, int nb, f32x4 x, f32x4& csum) {
-    const bool valid = e.ok && nb < P.N;               // N % 4 == 0: a lane's 4 columns are all in or all out
-    if (valid) {
-        if (P.bias_n) x += *(const f32x4*)(P.bias_n + nb);
-        if (P.alpha != 1.f) x *= P.alpha;
-        if (P.flags & BPM_GEMM_RELU) {
+// Fast epilogue of one wave's column block: rows (m0 + 16*b + r), b < NB, columns nb..nb+3.
+// Two phases.  Phase 1 issues EVERY side-operand load of the NB tiles back to back (bias, gate, residual or the
+// previous value for +=) from clamped, always-valid addresses; phase 2 does the arithmetic and the stores.
+// Interleaving them per tile (load, compute, store, load, ...) serialises one memory round trip per tile, because
+// the loads may alias the stores and cannot be hoisted by the compiler: measured 6.6 us of a 16 us workgroup.
+template <typename CT, int NB>
+BPM_DEV void epilogue_fast(const Prob& P, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB], f32x4& csum) {
+    const bool colok = nb < P.N;                        // N % 4 == 0: a lane's 4 columns are all in or all out
+    const uint32_t nbc = colok ? (uint32_t)nb : 0u;     // clamped column for the loads
+    const bool f32out = P.out_kind == BPM_OUT_F32;
+    const bool accum = f32out && (P.flags & BPM_GEMM_ACCUM);
+    typedef typename std::conditional<sizeof(CT) == 4, f32x4, bf16x4>::type gate_t;
+
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 addv[NB];
+    gate_t gt[NB];
+    if (P.bias_n) bias = *(const f32x4*)(P.bias_n + nbc);
+    if (P.gate) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = fmaxf(x[q], 0.f);
-        }
-        if (P.gate) {
-            f32x4 gt;
-            if constexpr (sizeof(CT) == 4) gt = *(const f32x4*)((const float*)P.gate + e.offg + nb);
-            else { const bf16x4 t = *(const bf16x4*)((const bf16_t*)P.gate + e.offg + nb); gt = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+        for (int b = 0; b < NB; ++b) gt[b] = *(const gate_t*)((const CT*)P.gate + rows[b].offg + nbc);
+    } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = gt[q] > 0.f ? x[q] * P.gate_scale : 0.f;
-        }
-        if (P.drop.thresh != 0) {                       // m*N + nb is even: two hash pairs
-            float d0, d1, d2, d3;
-            bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb, d0, d1);
-            bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb + 2u, d2, d3);
-            x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
-        }
-        csum += x;
-        if (P.resid) x += *(const f32x4*)(P.resid + e.offr + nb);
+        for (int b = 0; b < NB; ++b) gt[b] = gate_t{};
     }
-    if (P.out_kind == BPM_OUT_F32) {
-        if (!valid) return;
-        float* c = (float*)P.C + e.offc + nb;
-        if (P.flags & BPM_GEMM_ACCUM) x += *(const f32x4*)c;
-        *(f32x4*)c = x;
-    } else if (P.out_kind == BPM_OUT_CT) {
-        if (!e.ok || nb >= P.ldc) return;               // pad columns [N, ldc) receive zeros
-        if (!valid) x = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (sizeof(CT) == 4) *(f32x4*)((float*)P.C + e.offc + nb) = x;
-        else { bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3]; *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o; }
-    } else {                                            // head-major: one division per tile, heads advance by carry
-        if (!valid) return;
-        uint32_t h = (uint32_t)nb / (uint32_t)P.hdh, c = (uint32_t)nb - h * (uint32_t)P.hdh;
-        const uint32_t hstride = (uint32_t)(P.hT * P.hdhp);
-        CT* base = (CT*)P.C + e.hrow;
+    if (P.resid) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            base[h * hstride + c] = Tr<CT>::from_f(x[q]);
-            if (++c == (uint32_t)P.hdh) { c = 0; ++h; }
+        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)(P.resid + rows[b].offr + nbc);
+    } else if (accum) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)((const float*)P.C + rows[b].offc + nbc);
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) addv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const EpiRow& e = rows[b];
+        const bool valid = e.ok && colok;
+        f32x4 x = acc[b];
+        if (valid) {
+            x += bias;
+            if (P.alpha != 1.f) x *= P.alpha;
+            if (P.flags & BPM_GEMM_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = fmaxf(x[q], 0.f);
+            }
+            if (P.gate) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = (float)gt[b][q] > 0.f ? x[q] * P.gate_scale : 0.f;
+            }
+            if (P.drop.thresh != 0) {                   // m*N + nb is even: two hash pairs
+                float d0, d1, d2, d3;
+                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb, d0, d1);
+                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb + 2u, d2, d3);
+                x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
+            }
+            csum += x;
+            x += addv[b];
+        }
+        if (f32out) {
+            if (valid) *(f32x4*)((float*)P.C + e.offc + nb) = x;
+        } else if (P.out_kind == BPM_OUT_CT) {
+            if (e.ok && nb < P.ldc) {                   // pad columns [N, ldc) receive zeros
+                if (!valid) x = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (sizeof(CT) == 4) *(f32x4*)((float*)P.C + e.offc + nb) = x;
+                else { bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3]; *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o; }
+            }
+        } else if (valid) {                             // head-major: one division per tile, heads advance by carry
+            uint32_t h = (uint32_t)nb / (uint32_t)P.hdh, c = (uint32_t)nb - h * (uint32_t)P.hdh;
+            const uint32_t hstride = (uint32_t)(P.hT * P.hdhp);
+            CT* base = (CT*)P.C + e.hrow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                base[h * hstride + c] = Tr<CT>::from_f(x[q]);
+                if (++c == (uint32_t)P.hdh) { c = 0; ++h; }
+            }
         }
     }
 }
@@ -302,8 +352,7 @@ template <typename CT, int NB>
 BPM_DEV void epilogue_cols(const Prob& P, bool fast, bool lead, int m0, int r, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB]) {
     if (fast) {
         f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < NB; ++b) epilogue_fast<CT>(P, rows[b], nb, acc[b], cs);
+        epilogue_fast<CT, NB>(P, nb, acc, rows, cs);
         if (P.colsum) { float c4[4] = {cs[0], cs[1], cs[2], cs[3]}; flush_colsum(P, c4, nb, r); }
     } else {
         float csum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -414,8 +463,17 @@ BPM_DEV const Prob& pick_problem(const Group& grp, int& bid) {
 // ---------------------------------------------------------------------------
 // general tiled kernel
 // ---------------------------------------------------------------------------
+#ifdef BPM_GEMM_TRACE
+// debug build only: per-workgroup timestamps (100 MHz realtime counter) of the tiled kernel's phases
+__device__ unsigned long long g_trace[8192 * 16];
+#define BPM_TRACE(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && (slot) < 16) \
+        g_trace[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BPM_TRACE(slot) do { } while (0)
+#endif
+
 template <typename CT, bool XK, bool YK, int KSTEPS>
-__global__ __launch_bounds__(NTHREADS) void gemm_tiled_kernel(const Group grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TILED_MINW, BPM_TILED_MINW))) void gemm_tiled_kernel(const Group grp) {
     typedef Side<CT, XK, BM, KSTEPS, XK && !YK> SX;     // NN: X is k-contiguous beside a transposed-read Y
     typedef Side<CT, YK, BN, KSTEPS, false> SY;
     constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
@@ -424,6 +482,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiled_kernel(const Group grp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
+    BPM_TRACE(0);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const Prob& P = pick_problem(grp, bid);
     const int tiles = P.tiles_m * P.tiles_n;
@@ -451,6 +510,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiled_kernel(const Group grp) {
         SY::store(smem + SX::IMG_BYTES, ry, tid);
     }
     __syncthreads();
+    BPM_TRACE(1);
     int cur = 0;
 #pragma unroll 1
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
@@ -479,6 +539,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiled_kernel(const Group grp) {
             SY::store(nx + SX::IMG_BYTES, ry, tid);
         }
         __syncthreads();
+        BPM_TRACE(2 + kt - kt_lo);
         cur ^= 1;
     }
 
@@ -490,9 +551,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tiled_kernel(const Group grp) {
     EpiRow rows[TM];
 #pragma unroll
     for (int b = 0; b < TM; ++b) rows[b] = epi_row(P, mw + 16 * b + r);
+    BPM_TRACE(12);
 #pragma unroll
-    for (int a = 0; a < TN; ++a)       // colsum shuffles: uniform per workgroup, every lane takes part
+    for (int a = 0; a < TN; ++a) {     // colsum shuffles: uniform per workgroup, every lane takes part
         epilogue_cols<CT, TM>(P, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows);
+        BPM_TRACE(13 + a);
+    }
+#ifdef BPM_GEMM_TRACE
+    __builtin_amdgcn_s_waitcnt(0);     // stores issued; vmcnt drained
+    BPM_TRACE(15);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -650,8 +718,13 @@ int launch(int variant, bool astat, const Group& g, hipStream_t s) {
     } else {
         switch (variant) {
             case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD>), grid, block, 0, s, g); break;
-            case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, KS_FWD>), grid, block, 0, s, g); break;
-            case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, KS_WGRAD>), grid, block, 0, s, g); break;
+            case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, 1>), grid, block, 0, s, g); break;
+            case BPM_GEMM_TN:
+                // measured (MI355X, K = 4096 rows): with at least ~2 workgroups per CU the short stage wins
+                // (more resident workgroups hide the load latency); below that the long stage does
+                if (g.total_tiles >= 2 * 256) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1>), grid, block, 0, s, g);
+                else hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, KS_WGRAD>), grid, block, 0, s, g);
+                break;
             default: return BPM_ERR_ARG;
         }
     }
@@ -660,6 +733,13 @@ int launch(int variant, bool astat, const Group& g, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef BPM_GEMM_TRACE
+extern "C" int bpm_debug_trace(unsigned long long* out, int nblocks) {
+    if (nblocks > 8192) nblocks = 8192;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 16 * nblocks);
+}
+#endif
 
 extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs, int nprob, uint64_t seed, void* stream) {
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
