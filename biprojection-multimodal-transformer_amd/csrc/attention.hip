@@ -84,6 +84,35 @@ BPM_DEV void load_rows(char* img, const char* src, int row0, int nrows, int tid)
     }
 }
 
+// the same copy split in two: global -> registers (issued one tile ahead, behind the current tile's arithmetic)
+// and registers -> LDS image.  Loads are unconditional from a clamped row (row 0 always exists) and zeroed by
+// a select, so no branch sits between the load and its use.
+template <typename CT, int DHP, int ROWS>
+struct RowStage {
+    typedef Cfg<CT, DHP> C;
+    static constexpr int N = ROWS * C::CPR;
+    static constexpr int PT = (N + NTHREADS - 1) / NTHREADS;
+    u32x4 r[PT];
+    BPM_DEV void load(const char* src, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = tid + i * NTHREADS;
+            const int row = c / C::CPR, cc = c % C::CPR;
+            const bool ok = c < N && row0 + row < nrows;
+            const u32x4 v = *(const u32x4*)(src + (size_t)(ok ? row0 + row : 0) * C::ROWB + cc * 16);
+            r[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    BPM_DEV void store(char* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = tid + i * NTHREADS;
+            if (N % NTHREADS != 0 && c >= N) continue;
+            *(u32x4*)(img + (c / C::CPR) * C::STRIDE + (c % C::CPR) * 16) = r[i];
+        }
+    }
+};
+
 // operand chunk straight from a head-major global row (zero beyond nrows)
 template <typename CT, int DHP>
 BPM_DEV typename Tr<CT>::frag load_frag(const char* src, int row, int nrows, int ks, int g) {
@@ -142,13 +171,17 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
     const int lim_min = min(P.S, q0 + P.mask_off);     // every lane of the wave sees keys j < lim_min
     const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
+    const bool pair_ok = (P.S & 1) == 0;               // row starts are even: keys (2m, 2m+1) are hash pairs
 
+    RowStage<CT, DHP, KT> kst, vst;
+    if (ntile > 0) { kst.load(Kh, 0, P.S, tid); vst.load(Vh, 0, P.S, tid); }
 #pragma unroll 1
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
-        load_rows<CT, DHP, KT>(kimg, Kh, kt * KT, P.S, tid);
-        load_rows<CT, DHP, KT>(vimg, Vh, kt * KT, P.S, tid);
+        kst.store(kimg, tid);
+        vst.store(vimg, tid);
         __syncthreads();
+        if (kt + 1 < ntile) { kst.load(Kh, (kt + 1) * KT, P.S, tid); vst.load(Vh, (kt + 1) * KT, P.S, tid); }
 
         f32x4 st[4];
 #pragma unroll
@@ -184,10 +217,20 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
                 st[n][r] = p;
             }
         if (dropping) {
+            if (pair_ok) {                             // wave-uniform: (r, r+1) share one hash
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < 4; ++n) {
+                    float d0, d1, d2, d3;
+                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n), d0, d1);
+                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n + 2), d2, d3);
+                    st[n][0] *= d0; st[n][1] *= d1; st[n][2] *= d2; st[n][3] *= d3;
+                }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[n][r] *= bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[n][r] *= bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+            }
         }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -272,13 +315,17 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
     const int lim_min = min(P.S, q0 + P.mask_off);
     const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
+    const bool pair_ok = (P.S & 1) == 0;               // row starts are even: keys (2m, 2m+1) are hash pairs
 
+    RowStage<CT, DHP, KT> kst, vst;
+    if (ntile > 0) { kst.load(Kh, 0, P.S, tid); vst.load(Vh, 0, P.S, tid); }
 #pragma unroll 1
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
-        load_rows<CT, DHP, KT>(kimg, Kh, kt * KT, P.S, tid);
-        load_rows<CT, DHP, KT>(vimg, Vh, kt * KT, P.S, tid);
+        kst.store(kimg, tid);
+        vst.store(vimg, tid);
         __syncthreads();
+        if (kt + 1 < ntile) { kst.load(Kh, (kt + 1) * KT, P.S, tid); vst.load(Vh, (kt + 1) * KT, P.S, tid); }
         const int jb = kt * KT + 4 * g;
         const bool edge = kt * KT + KT > lim_min;
         const int rel = lim - jb;
@@ -291,14 +338,22 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
                 s_ = Tr<CT>::mma(read_rowfrag<CT>(kimg, C::STRIDE, 16 * n, s, lane), qf[s], s_);
                 dp = Tr<CT>::mma(read_rowfrag<CT>(vimg, C::STRIDE, 16 * n, s, lane), dof[s], dp);
             }
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (dropping) {
+                if (pair_ok) {
+                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n), dm[0], dm[1]);
+                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n + 2), dm[2], dm[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dm[r] = bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float e = fmaf(s_[r], LOG2E, lse2);
                 if (edge) e = (16 * n + r < rel) ? e : -INFINITY;      // exp2(-inf) = 0: masked before the exponential
                 const float p = fast_exp2(e);
-                float dpv = dp[r];
-                if (dropping) dpv *= bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
-                ds[n][r] = p * (dpv - delta);
+                ds[n][r] = p * (dp[r] * dm[r] - delta);
             }
         }
         // dQ^T += K^T dS^T
@@ -366,17 +421,28 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
     const int qt_hi = (P.T + QT - 1) / QT;
     const bool dropping = P.drop.thresh != 0;
 
+    RowStage<CT, DHP, QT> qst, dost;
+    float n_lse = 0.f, n_del = 0.f;                    // threads < QT: next tile's -lse*log2(e) and delta
+    const float* lse_h = P.lse + (size_t)bh * P.T;
+    const float* del_h = P.delta + (size_t)bh * P.T;
+    auto stage = [&](int qt) {
+        qst.load(Qh, qt * QT, P.T, tid);
+        dost.load(dOh, qt * QT, P.T, tid);
+        const int i = qt * QT + (tid & (QT - 1));
+        const bool ok = i < P.T;
+        const float l = lse_h[ok ? i : 0], dl = del_h[ok ? i : 0];
+        n_lse = ok ? -l * LOG2E : 0.f;
+        n_del = ok ? dl : 0.f;
+    };
+    if (qt_lo < qt_hi) stage(qt_lo);
 #pragma unroll 1
     for (int qt = qt_lo; qt < qt_hi; ++qt) {
         __syncthreads();
-        load_rows<CT, DHP, QT>(qimg, Qh, qt * QT, P.T, tid);
-        load_rows<CT, DHP, QT>(doimg, dOh, qt * QT, P.T, tid);
-        if (tid < QT) {
-            const int i = qt * QT + tid;
-            s_lse[tid] = i < P.T ? -P.lse[(size_t)bh * P.T + i] * LOG2E : 0.f;
-            s_del[tid] = i < P.T ? P.delta[(size_t)bh * P.T + i] : 0.f;
-        }
+        qst.store(qimg, tid);
+        dost.store(doimg, tid);
+        if (tid < QT) { s_lse[tid] = n_lse; s_del[tid] = n_del; }
         __syncthreads();
+        if (qt + 1 < qt_hi) stage(qt + 1);
         const bool edge = (qt * QT < ilo_max) || (qt * QT + QT > P.T);
         f32x4 pd[2], ds[2];
 #pragma unroll

@@ -309,6 +309,46 @@ __global__ __launch_bounds__(NT) void rows_cast_kernel(const Grp<CastP> grp) {
     if (P.colsum && c < P.C) atomicAdd(P.colsum + c, s);
 }
 
+// Column sums only (bias gradients from a gradient matrix already in HBM): 4-column vector loads, several rows
+// per pass and four passes in flight per thread, LDS reduction, one atomic per column and workgroup.
+constexpr int CSUM_ROWS = 128;
+
+template <typename CT>
+__global__ __launch_bounds__(NT) void colsum_kernel(const Grp<CastP> grp) {
+    __shared__ float red[NT * 4];
+    unsigned bid = blockIdx.x, nblk;
+    const CastP& P = pick(grp, bid, nblk);
+    const int CH = (P.C + 3) >> 2;                  // 4-column chunks per row (host: CH <= NT, rows padded to 4*CH)
+    const int rpp = NT / CH;                        // rows per pass
+    const int rr = threadIdx.x / CH, ch = threadIdx.x - rr * CH;
+    const int r0 = bid * CSUM_ROWS, r1 = min(P.R, r0 + CSUM_ROWS);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rr < rpp) {
+        auto ld = [&](int r) -> f32x4 {
+            const int rc = r < r1 ? r : r0;         // clamped, unconditional load; zeroed below
+            f32x4 v;
+            if (P.a_is_ct && sizeof(CT) == 2) {
+                const bf16x4 t = *(const bf16x4*)((const bf16_t*)P.a + (size_t)rc * P.lda + 4 * ch);
+                v = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            } else {
+                v = *(const f32x4*)((const float*)P.a + (size_t)rc * P.lda + 4 * ch);
+            }
+            return r < r1 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        for (int r = r0 + rr; r < r1; r += 4 * rpp) {
+            const f32x4 a0 = ld(r), a1 = ld(r + rpp), a2 = ld(r + 2 * rpp), a3 = ld(r + 3 * rpp);
+            acc += (a0 + a1) + (a2 + a3);
+        }
+    }
+    *(f32x4*)(red + 4 * threadIdx.x) = acc;
+    __syncthreads();
+    for (int c = threadIdx.x; c < P.C; c += NT) {
+        float sum = 0.f;
+        for (int q = 0; q < rpp; ++q) sum += red[4 * (q * CH) + c];
+        atomicAdd(P.colsum + c, sum);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Fusion-GMU gating (reference mmtr.py:189-195)
 //   out = z*tanh(a1)*x1 + (1-z)*tanh(a2)*x2,  z = sigmoid(ag)
@@ -528,6 +568,21 @@ extern "C" int bpm_rows_cast(int dtype, const bpm_cast_problem* q, int n, uint64
         p.cblk = (cols + NT - 1) / NT;
         p.drop = make_drop(s.drop_p, seed, s.drop_site);
         g.blk0[i + 1] = g.blk0[i] + (unsigned)p.cblk * ((s.R + CAST_ROWS - 1) / CAST_ROWS);
+    }
+    // all problems "column sums of an aligned matrix": the vectorised reduction kernel
+    bool only_sums = true;
+    for (int i = 0; i < n; ++i) {
+        const bpm_cast_problem& s = q[i];
+        const int ch = (s.C + 3) / 4;
+        const size_t esz = (s.a_is_ct && dtype == BPM_BF16) ? 2 : 4;
+        only_sums = only_sums && !s.dst_ct && !s.dst_f32 && !s.b && s.colsum && !(s.drop_p > 0.f) && ch <= NT &&
+                    s.lda >= 4 * ch && (s.lda % 4) == 0 && ((uintptr_t)s.a % (4 * esz)) == 0;
+    }
+    if (only_sums) {
+        for (int i = 0; i < n; ++i) g.blk0[i + 1] = g.blk0[i] + (unsigned)((q[i].R + CSUM_ROWS - 1) / CSUM_ROWS);
+        BPM_DISPATCH_CT(dtype, colsum_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
+        BPM_CHECK_LAUNCH();
+        return 0;
     }
     BPM_DISPATCH_CT(dtype, rows_cast_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
     BPM_CHECK_LAUNCH();
