@@ -121,6 +121,23 @@ def cpu_baseline(c, sample_B, steps):
                        f"{dt:.2f} s/step, torch {torch.__version__} CPU ops")
 
 
+KIND_TO_FAMILY = {"gemm_nt": "gemm_tiled_kernel<NT>", "gemm_nn": "gemm_tiled_kernel<NN>", "gemm_tn": "gemm_tiled_kernel<TN>",
+                  "attn_fwd": "attn_fwd_kernel", "attn_bwd_dq": "attn_bwd_dq_kernel", "attn_bwd_dkv": "attn_bwd_dkv_kernel"}
+
+
+def hbm_traffic(kind):
+    """HBM bytes per launch of the dominant kernel family, from the committed PMC passes (tools/pmc_traffic.sh:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same workload, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no measurement of this configuration is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][KIND_TO_FAMILY[kind]]
+        return round(k["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +239,7 @@ def main():
 
     if rank == 0:
         ach = work.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        traffic = hbm_traffic(dom) if (a.config == "cfg1" and a.precision == "bf16" and not a.batch) else None
         out = {
             "metric": "training samples/sec (fwd+bwd) BPMulT",
             "value": round(world * B * a.steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -233,7 +251,7 @@ def main():
                        "kernel_time_share_warmup_ms": {k: round(v[0], 2) for k, v in tot.items()}},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3,
                          "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if a.precision == "bf16" else 157.3), 4),
-                         "traffic": None, "launches": n.value, "avg_launch_ms": round(ms.value / max(n.value, 1), 4),
+                         "traffic": traffic, "launches": n.value, "avg_launch_ms": round(ms.value / max(n.value, 1), 4),
                          "flops_per_launch": work.value / max(n.value, 1)},
         }
         print("[bench] gpu part done: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline")}), file=sys.stderr, flush=True)

@@ -130,6 +130,8 @@ SIGNATURES = {
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
+    "bpm_stream_create": [_I, C.POINTER(C.c_void_p)],
+    "bpm_stream_priority_range": [C.POINTER(_I), C.POINTER(_I)],
     "bpm_prof_enable": [C.c_uint],
     "bpm_prof_collect": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)],
 }

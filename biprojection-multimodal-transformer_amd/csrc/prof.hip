@@ -64,3 +64,22 @@ extern "C" int bpm_prof_collect(int kind, double* total_ms, double* total_work, 
     *total_ms = ms; *total_work = work; *launches = n;
     return 0;
 }
+
+// A HIP stream at the lowest (low_priority != 0) or default priority the device offers, for the engine's
+// off-critical-path work: the dispatcher then fills CUs from the main stream's kernels first.
+extern "C" int bpm_stream_create(int low_priority, void** out) {
+    if (!out) return BPM_ERR_ARG;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return (int)e;
+    hipStream_t s;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, low_priority ? least : 0);
+    if (e != hipSuccess) return (int)e;
+    *out = (void*)s;
+    return 0;
+}
+
+extern "C" int bpm_stream_priority_range(int* least, int* greatest) {
+    if (!least || !greatest) return BPM_ERR_ARG;
+    return (int)hipDeviceGetStreamPriorityRange(least, greatest);
+}

@@ -225,9 +225,16 @@ _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
+    """One side stream per device, created through the C ABI at the device's LOWEST priority (the dispatcher
+    then fills CUs from the main stream first); BPMULT_SIDE_PRIORITY=normal keeps the default priority."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
+        from . import _lib
+        low = os.environ.get("BPMULT_SIDE_PRIORITY", "low") != "normal"
+        out = C.c_void_p()
+        with torch.cuda.device(key):
+            _lib.check(_lib.lib().bpm_stream_create(int(low), C.byref(out)), "bpm_stream_create")
+        _side_streams[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key))
     return _side_streams[key]
 
 

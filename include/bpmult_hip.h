@@ -205,6 +205,12 @@ typedef struct bpm_gmu_problem {
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
+/* Engine plumbing (no reference counterpart): a non-blocking HIP stream at the device's lowest priority
+ * (low_priority != 0) or at the default priority.  The host engine puts weight-gradient GEMMs and the
+ * key/value-side chain there so that the dispatcher serves the critical-path stream first. */
+int bpm_stream_create(int low_priority, void** out_stream);
+int bpm_stream_priority_range(int* least, int* greatest);
+
 /* ------------------------------------------------------------------------
  * Launch profiler (measurement aid for bench.py; no reference counterpart).
  * While bit `kind` of the mask is set, every launch of that kernel kind is

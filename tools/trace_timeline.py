@@ -16,13 +16,15 @@ def short(name):
                   r"pack_weights_kernel)", name)
     if m:
         k = m.group(1)
-        if k == "gemm_tiled_kernel":
+        if k == "gemm_tiled_kernel":      # needs mangled names (rocprofv3 -M): the demangler garbles __bf16 templates
             if "Lb0ELb0E" in name or "false, false" in name:
                 k += "<TN>"
             elif "Lb1ELb1E" in name or "true, true" in name:
                 k += "<NT>"
-            else:
+            elif "Lb1ELb0E" in name or "true, false" in name:
                 k += "<NN>"
+            else:
+                k += "<?>"
         return k
     if "Cijk" in name:
         return "hipblaslt"
