@@ -68,6 +68,12 @@ constexpr int TN = BN / WN / 16;          // 2 along n
 #ifndef BPM_TILED_MINW
 #define BPM_TILED_MINW 4
 #endif
+#ifndef BPM_DEEP_TN
+#define BPM_DEEP_TN 2
+#endif
+#ifndef BPM_DEEP_FWD
+#define BPM_DEEP_FWD 1
+#endif
 #ifndef BPM_KS_FWD
 #define BPM_KS_FWD 1
 #endif
@@ -388,8 +394,13 @@ struct Side {
     static constexpr int PER_THREAD = (NCHUNK + NTHREADS - 1) / NTHREADS;
 
     // global -> registers.  rows_bound: valid rows of this side (M or N); k_hi: contraction bound; ld: leading dim.
-    static BPM_DEV void load(const char* base, int ld, int row0, int rows_bound, int k0, int k_hi,
-                             u32x4 (&reg)[PER_THREAD], int tid) {
+    // Loads are UNCONDITIONAL from a clamped offset (0 = the matrix origin) and the validity of each chunk comes
+    // back as a bit mask that store() applies: a guarded load (`ok ? *p : 0`) compiles to a branch around the
+    // load plus a zero fill of its destination, and the waitcnt pass then drains every outstanding load at the
+    // loop head -- which serialises the prefetch pipeline.
+    static BPM_DEV uint32_t load(const char* base, int ld, int row0, int rows_bound, int k0, int k_hi,
+                                 u32x4 (&reg)[PER_THREAD], int tid) {
+        uint32_t mask = 0;
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int c = tid + i * NTHREADS;
@@ -408,14 +419,17 @@ struct Side {
                 off = ((size_t)(k0 + kr) * ld + col) * SZ;
             }
             if (NCHUNK % NTHREADS) ok = ok && (c < NCHUNK);
-            reg[i] = ok ? *(const u32x4*)(base + off) : u32x4{0u, 0u, 0u, 0u};
+            reg[i] = *(const u32x4*)(base + (ok ? off : (size_t)0));
+            mask |= ok ? (1u << i) : 0u;
         }
+        return mask;
     }
-    static BPM_DEV void store(char* img, const u32x4 (&reg)[PER_THREAD], int tid) {
+    static BPM_DEV void store(char* img, const u32x4 (&reg)[PER_THREAD], uint32_t mask, int tid) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int c = tid + i * NTHREADS;
             if ((NCHUNK % NTHREADS) && c >= NCHUNK) continue;
+            const u32x4 v = ((mask >> i) & 1u) ? reg[i] : u32x4{0u, 0u, 0u, 0u};
             int dst;
             if (KCONTIG) {
                 const int row = c / (BKB / 16), kc = c % (BKB / 16);
@@ -423,8 +437,8 @@ struct Side {
                     static_assert(!PERM || KSTEPS == 1, "PERM images hold one k-step");
                     const int h0 = 2 * kc, h1 = 2 * kc + 1, sw = swz4(row);
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    *(u32x2*)(img + row * 64 + (((h0 & 3) ^ sw) << 4) + ((h0 >> 2) << 3)) = u32x2{reg[i][0], reg[i][1]};
-                    *(u32x2*)(img + row * 64 + (((h1 & 3) ^ sw) << 4) + ((h1 >> 2) << 3)) = u32x2{reg[i][2], reg[i][3]};
+                    *(u32x2*)(img + row * 64 + (((h0 & 3) ^ sw) << 4) + ((h0 >> 2) << 3)) = u32x2{v[0], v[1]};
+                    *(u32x2*)(img + row * 64 + (((h1 & 3) ^ sw) << 4) + ((h1 >> 2) << 3)) = u32x2{v[2], v[3]};
                     continue;
                 }
                 dst = row * ROW_STRIDE + (SWZ ? (kc ^ swz4(row)) : kc) * 16;
@@ -433,7 +447,7 @@ struct Side {
                 const int kr = c / CPR, cc = c % CPR;
                 dst = kr * STRIDE + cc * 16;
             }
-            *(u32x4*)(img + dst) = reg[i];
+            *(u32x4*)(img + dst) = v;
         }
     }
     // operand chunk for the 16 rows starting at r0, k-step ks of the stage
@@ -472,7 +486,7 @@ __device__ unsigned long long g_trace[8192 * 16];
 #define BPM_TRACE(slot) do { } while (0)
 #endif
 
-template <typename CT, bool XK, bool YK, int KSTEPS>
+template <typename CT, bool XK, bool YK, int KSTEPS, bool DEEP = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TILED_MINW, BPM_TILED_MINW))) void gemm_tiled_kernel(const Group grp) {
     typedef Side<CT, XK, BM, KSTEPS, XK && !YK> SX;     // NN: X is k-contiguous beside a transposed-read Y
     typedef Side<CT, YK, BN, KSTEPS, false> SY;
@@ -502,24 +516,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 rx[SX::PER_THREAD], ry[SY::PER_THREAD];
-    if (kt_lo < kt_hi) {
-        SX::load(P.X, P.ldx, m0, P.M, kt_lo * BK, P.K, rx, tid);
-        SY::load(P.Y, P.ldy, n0, P.N, kt_lo * BK, P.K, ry, tid);
-        SX::store(smem, rx, tid);
-        SY::store(smem + SX::IMG_BYTES, ry, tid);
-    }
-    __syncthreads();
-    BPM_TRACE(1);
-    int cur = 0;
-#pragma unroll 1
-    for (int kt = kt_lo; kt < kt_hi; ++kt) {
-        const bool more = kt + 1 < kt_hi;
-        if (more) {
-            SX::load(P.X, P.ldx, m0, P.M, (kt + 1) * BK, P.K, rx, tid);
-            SY::load(P.Y, P.ldy, n0, P.N, (kt + 1) * BK, P.K, ry, tid);
-        }
-        const char* ix = smem + cur * STAGE;
+    auto compute = [&](const char* ix) {
         const char* iy = ix + SX::IMG_BYTES;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -533,14 +530,72 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
 #pragma unroll
                 for (int b = 0; b < TM; ++b) acc[a][b] = Tr<CT>::mma(fy[a], fx[b], acc[a][b]);
         }
-        if (more) {
-            char* nx = smem + (cur ^ 1) * STAGE;
-            SX::store(nx, rx, tid);
-            SY::store(nx + SX::IMG_BYTES, ry, tid);
-        }
+    };
+
+    const char* const Xp = P.X;
+    const char* const Yp = P.Y;
+    const int ldx = P.ldx, ldy = P.ldy, Mb = P.M, Nb = P.N, Kb = P.K;
+    if constexpr (DEEP) {
+        // Two register sets: the loads of k-stage kt+2 are issued before the arithmetic of stage kt, so two
+        // stages are in flight per workgroup and a stage's L2 round trip is spread over two iterations.
+        u32x4 rx0[SX::PER_THREAD], ry0[SY::PER_THREAD], rx1[SX::PER_THREAD], ry1[SY::PER_THREAD];
+        uint32_t mx0 = 0, my0 = 0, mx1 = 0, my1 = 0;
+        auto ld0 = [&](int kt) { mx0 = SX::load(Xp, ldx, m0, Mb, kt * BK, Kb, rx0, tid); my0 = SY::load(Yp, ldy, n0, Nb, kt * BK, Kb, ry0, tid); };
+        auto ld1 = [&](int kt) { mx1 = SX::load(Xp, ldx, m0, Mb, kt * BK, Kb, rx1, tid); my1 = SY::load(Yp, ldy, n0, Nb, kt * BK, Kb, ry1, tid); };
+        auto st0 = [&](char* img) { SX::store(img, rx0, mx0, tid); SY::store(img + SX::IMG_BYTES, ry0, my0, tid); };
+        auto st1 = [&](char* img) { SX::store(img, rx1, mx1, tid); SY::store(img + SX::IMG_BYTES, ry1, my1, tid); };
+        // stage kt lives in set (kt - kt_lo) & 1
+        // loads past kt_hi are issued too (every chunk masked off, address clamped to the origin): a load inside a
+        // conditional makes the waitcnt pass assume the shorter queue and drain the newer stage with the older one
+        ld0(kt_lo);
+        st0(smem);
+        ld1(kt_lo + 1);
         __syncthreads();
-        BPM_TRACE(2 + kt - kt_lo);
-        cur ^= 1;
+        BPM_TRACE(1);
+        int cur = 0;
+#pragma unroll 1
+        for (int kt = kt_lo; kt < kt_hi; kt += 2) {
+            // even step: LDS holds kt, set1 carries kt+1, set0 is free -> kt+2
+            ld0(kt + 2);
+            compute(smem + cur * STAGE);
+            if (kt + 1 < kt_hi) st1(smem + (cur ^ 1) * STAGE);
+            __syncthreads();
+            BPM_TRACE(2 + kt - kt_lo);
+            cur ^= 1;
+            if (kt + 1 >= kt_hi) break;
+            // odd step: LDS holds kt+1, set0 carries kt+2, set1 is free -> kt+3
+            ld1(kt + 3);
+            compute(smem + cur * STAGE);
+            if (kt + 2 < kt_hi) st0(smem + (cur ^ 1) * STAGE);
+            __syncthreads();
+            BPM_TRACE(3 + kt - kt_lo);
+            cur ^= 1;
+        }
+    } else {
+        u32x4 rx[SX::PER_THREAD], ry[SY::PER_THREAD];
+        uint32_t mx = 0, my = 0;
+        mx = SX::load(Xp, ldx, m0, Mb, kt_lo * BK, Kb, rx, tid);
+        my = SY::load(Yp, ldy, n0, Nb, kt_lo * BK, Kb, ry, tid);
+        SX::store(smem, rx, mx, tid);
+        SY::store(smem + SX::IMG_BYTES, ry, my, tid);
+        __syncthreads();
+        BPM_TRACE(1);
+        int cur = 0;
+#pragma unroll 1
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            const bool more = kt + 1 < kt_hi;
+            mx = SX::load(Xp, ldx, m0, Mb, (kt + 1) * BK, Kb, rx, tid);      // unconditional (masked off past K)
+            my = SY::load(Yp, ldy, n0, Nb, (kt + 1) * BK, Kb, ry, tid);
+            compute(smem + cur * STAGE);
+            if (more) {
+                char* nx = smem + (cur ^ 1) * STAGE;
+                SX::store(nx, rx, mx, tid);
+                SY::store(nx + SX::IMG_BYTES, ry, my, tid);
+            }
+            __syncthreads();
+            BPM_TRACE(2 + kt - kt_lo);
+            cur ^= 1;
+        }
     }
 
     const int r = lane & 15, g = lane >> 4;
@@ -717,13 +772,14 @@ int launch(int variant, bool astat, const Group& g, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_astat_kernel<CT, false, AS_BN_NN>), grid, block, 0, s, g);
     } else {
         switch (variant) {
-            case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD>), grid, block, 0, s, g); break;
-            case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, 1>), grid, block, 0, s, g); break;
+            case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD, BPM_DEEP_FWD != 0>), grid, block, 0, s, g); break;
+            case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, 1, BPM_DEEP_FWD != 0>), grid, block, 0, s, g); break;
             case BPM_GEMM_TN:
                 // measured (MI355X, K = 4096 rows): with at least ~2 workgroups per CU the short stage wins
                 // (more resident workgroups hide the load latency); below that the long stage does
-                if (g.total_tiles >= 2 * 256) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1>), grid, block, 0, s, g);
-                else hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, KS_WGRAD>), grid, block, 0, s, g);
+                if (g.total_tiles >= 2 * 256) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1, BPM_DEEP_TN != 0>), grid, block, 0, s, g);
+                else if (BPM_DEEP_TN == 2) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1, true>), grid, block, 0, s, g);
+                else hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, KS_WGRAD, false>), grid, block, 0, s, g);
                 break;
             default: return BPM_ERR_ARG;
         }

@@ -25,6 +25,13 @@ for _ in range(G):
         bias = torch.randn(4 * d, device=dev)
         keep += [A_, B_, C_, bias]
         probs.append(ops.gemm_problem(A_, B_, C_, R, 4 * d, d, ld, ld, ld4, out_kind=OUT_CT, flags=F_RELU, drop_p=0.1, drop_site=3, bias_n=bias))
+    elif which == "wgrad":   # dW[4d, d] = dh1^T xn2 : TN, K = R
+        A_, B_, C_ = rc(R, ld4), rc(R, ld), torch.zeros(4 * d, d, device=dev)
+        keep += [A_, B_, C_]
+        probs.append(ops.gemm_problem(A_, B_, C_, 4 * d, d, R, ld4, ld, d, flags=ops.F_ACCUM))
+        A2, B2, C2 = rc(R, ld), rc(R, ld4), torch.zeros(d, 4 * d, device=dev)
+        keep += [A2, B2, C2]
+        probs.append(ops.gemm_problem(A2, B2, C2, d, 4 * d, R, ld, ld4, 4 * d, flags=ops.F_ACCUM))
     else:   # fc2
         A_, B_, C_ = rc(R, ld4), rc(d, ld4), torch.zeros(R, d, device=dev)
         bias, res = torch.randn(d, device=dev), torch.randn(R, d, device=dev)
@@ -32,7 +39,7 @@ for _ in range(G):
         probs.append(ops.gemm_problem(A_, B_, C_, R, d, 4 * d, ld4, ld4, d, drop_p=0.1, drop_site=3, bias_n=bias, resid=res, ldr=d))
 arr = ops.array(ops.GemmProblem, probs)
 for _ in range(3):
-    ops.gemm_grouped(BPM_BF16, GEMM_NT, arr, 7)
+    ops.gemm_grouped(BPM_BF16, ops.GEMM_TN if which == "wgrad" else GEMM_NT, arr, 7)
 torch.cuda.synchronize()
 lib = _lib.lib()
 lib.bpm_debug_trace.argtypes = [C.c_void_p, C.c_int]
