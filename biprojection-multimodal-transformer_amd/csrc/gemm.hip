@@ -450,6 +450,32 @@ struct Side {
             *(u32x4*)(img + dst) = v;
         }
     }
+    // Hardware-bounded loader (FAST): one 32-bit byte offset per chunk, computed once; the k position of a stage
+    // goes into the scalar offset of the buffer load and the range check of the buffer descriptor returns zeros
+    // past the end of the matrix (rows >= M of a k-contiguous operand, k >= K of a k-strided one).  Needs the
+    // caller's BPM_GEMM_KPAD_ZERO promise for the k tail of k-contiguous rows.  No per-iteration address or mask
+    // arithmetic is left in the k loop (it was ~2/3 of the loop's VALU instructions).
+    static BPM_DEV void voffsets(int ld, int row0, int tid, int (&voff)[PER_THREAD]) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int c = tid + i * NTHREADS;
+            int off;
+            if (KCONTIG) {
+                const int row = c / (BKB / 16), kc = c % (BKB / 16);
+                off = (row0 + row) * ld * SZ + kc * 16;
+            } else {
+                constexpr int CPR = ROWS * SZ / 16;
+                const int kr = c / CPR, cc = c % CPR;
+                off = (kr * ld + row0 + cc * EPC) * SZ;
+            }
+            voff[i] = ((NCHUNK % NTHREADS) && c >= NCHUNK) ? 0x7FFFFFF0 : off;
+        }
+    }
+    static BPM_DEV int stage_step(int ld) { return KCONTIG ? BKB : BK * ld * SZ; }     // bytes between k stages
+    static BPM_DEV void load_fast(__amdgpu_buffer_rsrc_t rsrc, const int (&voff)[PER_THREAD], int soff, u32x4 (&reg)[PER_THREAD]) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) reg[i] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
+    }
     // operand chunk for the 16 rows starting at r0, k-step ks of the stage
     static BPM_DEV typename Tr<CT>::frag frag(const char* img, int r0, int ks, int lane) {
         if (KCONTIG) {
@@ -486,7 +512,7 @@ __device__ unsigned long long g_trace[8192 * 16];
 #define BPM_TRACE(slot) do { } while (0)
 #endif
 
-template <typename CT, bool XK, bool YK, int KSTEPS, bool DEEP = false>
+template <typename CT, bool XK, bool YK, int KSTEPS, bool DEEP = false, bool FAST = false>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TILED_MINW, BPM_TILED_MINW))) void gemm_tiled_kernel(const Group grp) {
     typedef Side<CT, XK, BM, KSTEPS, XK && !YK> SX;     // NN: X is k-contiguous beside a transposed-read Y
     typedef Side<CT, YK, BN, KSTEPS, false> SY;
@@ -535,13 +561,35 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
     const char* const Xp = P.X;
     const char* const Yp = P.Y;
     const int ldx = P.ldx, ldy = P.ldy, Mb = P.M, Nb = P.N, Kb = P.K;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsx, rsy;
+    [[maybe_unused]] int vx[SX::PER_THREAD], vy[SY::PER_THREAD];
+    [[maybe_unused]] int stepx = 0, stepy = 0;
+    if constexpr (FAST) {
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)Xp, 0, (XK ? Mb : Kb) * ldx * (int)sizeof(CT), 0x00020000);
+        rsy = __builtin_amdgcn_make_buffer_rsrc((void*)Yp, 0, (YK ? Nb : Kb) * ldy * (int)sizeof(CT), 0x00020000);
+        SX::voffsets(ldx, m0, tid, vx);
+        SY::voffsets(ldy, n0, tid, vy);
+        stepx = SX::stage_step(ldx);
+        stepy = SY::stage_step(ldy);
+    }
+    // stage kt -> registers; returns nothing, masks by reference (all ones on the hardware-bounded path)
+    auto LD = [&](int kt, u32x4 (&rx_)[SX::PER_THREAD], u32x4 (&ry_)[SY::PER_THREAD], uint32_t& mx_, uint32_t& my_) {
+        if constexpr (FAST) {
+            SX::load_fast(rsx, vx, kt * stepx, rx_);
+            SY::load_fast(rsy, vy, kt * stepy, ry_);
+            mx_ = 0xFFFFFFFFu; my_ = 0xFFFFFFFFu;
+        } else {
+            mx_ = SX::load(Xp, ldx, m0, Mb, kt * BK, Kb, rx_, tid);
+            my_ = SY::load(Yp, ldy, n0, Nb, kt * BK, Kb, ry_, tid);
+        }
+    };
     if constexpr (DEEP) {
         // Two register sets: the loads of k-stage kt+2 are issued before the arithmetic of stage kt, so two
         // stages are in flight per workgroup and a stage's L2 round trip is spread over two iterations.
         u32x4 rx0[SX::PER_THREAD], ry0[SY::PER_THREAD], rx1[SX::PER_THREAD], ry1[SY::PER_THREAD];
         uint32_t mx0 = 0, my0 = 0, mx1 = 0, my1 = 0;
-        auto ld0 = [&](int kt) { mx0 = SX::load(Xp, ldx, m0, Mb, kt * BK, Kb, rx0, tid); my0 = SY::load(Yp, ldy, n0, Nb, kt * BK, Kb, ry0, tid); };
-        auto ld1 = [&](int kt) { mx1 = SX::load(Xp, ldx, m0, Mb, kt * BK, Kb, rx1, tid); my1 = SY::load(Yp, ldy, n0, Nb, kt * BK, Kb, ry1, tid); };
+        auto ld0 = [&](int kt) { LD(kt, rx0, ry0, mx0, my0); };
+        auto ld1 = [&](int kt) { LD(kt, rx1, ry1, mx1, my1); };
         auto st0 = [&](char* img) { SX::store(img, rx0, mx0, tid); SY::store(img + SX::IMG_BYTES, ry0, my0, tid); };
         auto st1 = [&](char* img) { SX::store(img, rx1, mx1, tid); SY::store(img + SX::IMG_BYTES, ry1, my1, tid); };
         // stage kt lives in set (kt - kt_lo) & 1
@@ -574,8 +622,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
     } else {
         u32x4 rx[SX::PER_THREAD], ry[SY::PER_THREAD];
         uint32_t mx = 0, my = 0;
-        mx = SX::load(Xp, ldx, m0, Mb, kt_lo * BK, Kb, rx, tid);
-        my = SY::load(Yp, ldy, n0, Nb, kt_lo * BK, Kb, ry, tid);
+        LD(kt_lo, rx, ry, mx, my);
         SX::store(smem, rx, mx, tid);
         SY::store(smem + SX::IMG_BYTES, ry, my, tid);
         __syncthreads();
@@ -584,8 +631,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
 #pragma unroll 1
         for (int kt = kt_lo; kt < kt_hi; ++kt) {
             const bool more = kt + 1 < kt_hi;
-            mx = SX::load(Xp, ldx, m0, Mb, (kt + 1) * BK, Kb, rx, tid);      // unconditional (masked off past K)
-            my = SY::load(Yp, ldy, n0, Nb, (kt + 1) * BK, Kb, ry, tid);
+            LD(kt + 1, rx, ry, mx, my);                                       // unconditional (masked off past K)
             compute(smem + cur * STAGE);
             if (more) {
                 char* nx = smem + (cur ^ 1) * STAGE;
@@ -765,8 +811,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_astat_kernel(const Group grp) {
 }
 
 template <typename CT>
-int launch(int variant, bool astat, const Group& g, hipStream_t s) {
+int launch(int variant, bool astat, bool fast, const Group& g, hipStream_t s) {
     dim3 grid(g.total_tiles), block(NTHREADS);
+    if (!astat && fast) {
+        switch (variant) {
+            case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD, BPM_DEEP_FWD != 0, true>), grid, block, 0, s, g); break;
+            case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, 1, BPM_DEEP_FWD != 0, true>), grid, block, 0, s, g); break;
+            case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1, true, true>), grid, block, 0, s, g); break;
+            default: return BPM_ERR_ARG;
+        }
+        BPM_CHECK_LAUNCH();
+        return 0;
+    }
     if (astat) {
         if (variant == BPM_GEMM_NT) hipLaunchKernelGGL((gemm_astat_kernel<CT, true, AS_BN_NT>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_astat_kernel<CT, false, AS_BN_NN>), grid, block, 0, s, g);
@@ -867,5 +923,19 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     double flops = 0;
     for (int i = 0; i < nprob; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * probs[i].K;
     BpmProfScope prof(BPM_K_GEMM_NT + variant, s, flops);
-    return dtype == BPM_BF16 ? launch<bf16_t>(variant, astat, g, s) : launch<float>(variant, astat, g, s);
+    // hardware-bounded loader: every problem promises zero k padding, k-contiguous rows are whole k stages and the
+    // matrices fit 31-bit byte offsets
+    static const bool no_fast = getenv("BPM_NO_FASTLD") != nullptr;
+    bool fast = !no_fast;
+    for (int i = 0; i < nprob && fast; ++i) {
+        const bpm_gemm_problem& q = probs[i];
+        const bool xk = variant != BPM_GEMM_TN, yk = variant == BPM_GEMM_NT;
+        const int stage_b = 64 * (variant == BPM_GEMM_NT ? KS_FWD : 1);
+        fast = (q.flags & BPM_GEMM_KPAD_ZERO) != 0;
+        if (xk) fast = fast && ((long)q.lda * sz) % stage_b == 0 && (long)q.K <= q.lda;
+        if (yk) fast = fast && ((long)q.ldb * sz) % stage_b == 0 && (long)q.K <= q.ldb;
+        const long bx = (long)(xk ? q.M : q.K) * q.lda * sz, by = (long)(yk ? q.N : q.K) * q.ldb * sz;
+        fast = fast && bx < (1l << 31) - 65536 && by < (1l << 31) - 65536;
+    }
+    return dtype == BPM_BF16 ? launch<bf16_t>(variant, astat, fast, g, s) : launch<float>(variant, astat, fast, g, s);
 }

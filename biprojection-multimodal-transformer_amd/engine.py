@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
-from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,
+from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,
                    AttnProblem, CastProblem, EmbedProblem, GemmProblem, GmuProblem, LnProblem, PackDesc, PackProblem)
 from .ops import pad32
 
@@ -307,6 +307,10 @@ class EncoderGroupPlan:
         return f"{e.prefix}layers.{i}.{leaf}"
 
     def _gemm(self, variant, probs):
+        # every operand of the encoder GEMMs is a CT buffer written by this library (LayerNorm / cast / epilogue /
+        # attention outputs into zero-initialised padded rows, packed weight shadows): the k padding is zero
+        for p in probs:
+            p.flags |= F_KPAD
         return (ops.gemm_grouped, self.dtype, variant, ops.array(GemmProblem, probs))
 
     # -- forward tables ---------------------------------------------------------

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, MAX_GROUP, OUT_CT,
+from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, MAX_GROUP, OUT_CT,
                    OUT_F32, OUT_HEADS, AttnProblem, CastProblem, EmbedProblem, GemmProblem, GmuProblem,
                    LnProblem, PackProblem)
 

@@ -54,7 +54,10 @@ const char* bpm_error_string(int code);
  * ---------------------------------------------------------------------- */
 enum { BPM_GEMM_NT = 0, BPM_GEMM_NN = 1, BPM_GEMM_TN = 2 };
 enum { BPM_OUT_F32 = 0, BPM_OUT_CT = 1, BPM_OUT_HEADS = 2 };
-enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4 };
+/* BPM_GEMM_KPAD_ZERO: the caller promises that every row of a k-contiguous operand (A of NT/NN, B of NT) is
+ * readable up to its leading dimension and holds ZEROS in [K, ld) -- what every CT buffer written by this
+ * library satisfies.  It lets the kernel use hardware-bounded buffer loads with no k-tail masking. */
+enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4, BPM_GEMM_KPAD_ZERO = 8 };
 
 typedef struct bpm_gemm_problem {
     const void* A;          /* CT */

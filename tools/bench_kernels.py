@@ -92,7 +92,7 @@ def main():
             if out_kind == OUT_HEADS:
                 extra["heads"] = (B, H, M // B, dh, dhp)
             keep.extend([A_, B_, C_] + list(extra.values()))
-            probs.append(ops.gemm_problem(A_, B_, C_, M, Nn, K, lda, ldb, ldc, out_kind=out_kind, flags=kw.get("flags", 0),
+            probs.append(ops.gemm_problem(A_, B_, C_, M, Nn, K, lda, ldb, ldc, out_kind=out_kind, flags=kw.get("flags", 0) | (0 if os.environ.get("NO_KPAD") else 8),
                                           drop_p=kw.get("drop_p", 0.0), drop_site=3, splitk=kw.get("splitk", 1), **extra))
         arr = ops.array(ops.GemmProblem, probs)
         keep.append(arr)
