@@ -78,7 +78,19 @@ class PackProblem(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int),
-                ("ld", C.c_int), ("src_ld", C.c_int), ("dst_ld", C.c_int), ("blk0", C.c_uint)]
+                ("ld", C.c_int), ("src_ld", C.c_int), ("dst_ld", C.c_int), ("blk0", C.c_uint),
+                ("colscale", C.c_void_p)]
+
+
+class FoldDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("beta", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int), ("ldw", C.c_int), ("blk0", C.c_uint)]
+
+
+class UnfoldDesc(C.Structure):
+    _fields_ = [("dWf", C.c_void_p), ("dbf", C.c_void_p), ("W", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("dW", C.c_void_p), ("dbias", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int), ("ldw", C.c_int), ("blk0", C.c_uint)]
 
 
 class EmbedProblem(C.Structure):
@@ -123,6 +135,8 @@ SIGNATURES = {
     "bpm_pack_rows_fwd": [_I, C.POINTER(PackProblem), _I, _U64, _P],
     "bpm_pack_rows_bwd": [C.POINTER(PackProblem), _I, _U64, _P],
     "bpm_pack_weights": [_I, _P, _I, C.c_uint, _P],
+    "bpm_fold_bias": [C.c_void_p, _I, C.c_uint, _P],
+    "bpm_unfold_grads": [C.c_void_p, _I, C.c_uint, _P],
     "bpm_embed_pos_fwd": [C.POINTER(EmbedProblem), _I, _P, _I, _I, _F, _U64, _P],
     "bpm_embed_pos_bwd": [C.POINTER(EmbedProblem), _I, _I, _F, _U64, _P],
     "bpm_ln_fwd": [_I, C.POINTER(LnProblem), _I, _I, _F, _P],

@@ -105,8 +105,55 @@ __global__ void pack_weights_kernel(const bpm_pack_desc* __restrict__ tab, int n
         if (i >= total) break;
         const int c = (int)(i % d.ld);
         const size_t r = i / d.ld;
-        put<CT>(d.dst, r * d.dst_ld + c, c < d.cols ? src[r * d.src_ld + c] : 0.f);
+        float v = 0.f;
+        if (c < d.cols) {
+            v = src[r * d.src_ld + c];
+            if (d.colscale) v *= d.colscale[c];
+        }
+        put<CT>(d.dst, r * d.dst_ld + c, v);
     }
+}
+
+template <typename D>
+BPM_DEV const D& find_desc(const D* __restrict__ tab, int ndesc, unsigned bid) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    return tab[lo];
+}
+
+// folded bias: out[n] = b[n] + W[n,:] . beta   (one wave per row)
+__global__ __launch_bounds__(NT) void fold_bias_kernel(const bpm_fold_desc* __restrict__ tab, int ndesc) {
+    const bpm_fold_desc d = find_desc(tab, ndesc, blockIdx.x);
+    const int row = (int)(blockIdx.x - d.blk0) * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= d.rows) return;
+    float s = 0.f;
+    for (int c = lane; c < d.cols; c += 64) s += d.W[(size_t)row * d.ldw + c] * d.beta[c];
+    s = wave_sum(s);
+    if (lane == 0) d.out[row] = s + (d.b ? d.b[row] : 0.f);
+}
+
+// gradients of the real parameters from the folded ones (see bpm_unfold_desc)
+constexpr int UNF_ROWS = 16;
+__global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc* __restrict__ tab, int ndesc) {
+    const bpm_unfold_desc d = find_desc(tab, ndesc, blockIdx.x);
+    const int r0 = (int)(blockIdx.x - d.blk0) * UNF_ROWS, r1 = min(d.rows, r0 + UNF_ROWS);
+    for (int c = threadIdx.x; c < d.cols; c += NT) {
+        const float g = d.gamma[c], bt = d.beta[c];
+        float ag = 0.f, ab = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const float f = d.dWf[(size_t)r * d.cols + c], w = d.W[(size_t)r * d.ldw + c], db = d.dbf[r];
+            d.dW[(size_t)r * d.ldw + c] += f * g + db * bt;
+            ag += f * w;
+            ab += db * w;
+        }
+        atomicAdd(d.dgamma + c, ag);
+        atomicAdd(d.dbeta + c, ab);
+    }
+    if ((int)threadIdx.x < r1 - r0) d.dbias[r0 + threadIdx.x] += d.dbf[r0 + threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------
@@ -462,6 +509,20 @@ static int fill_embed(Grp<EmbP>& g, const bpm_embed_problem* q, int n, int d, ui
         p.drop = make_drop(q[i].drop_p, seed, q[i].drop_site);
         g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)p.T * p.B * d, NT * 4, CAP);
     }
+    return 0;
+}
+
+extern "C" int bpm_fold_bias(const bpm_fold_desc* table_dev, int ndesc, unsigned total_blocks, void* stream) {
+    if (!table_dev || ndesc < 1 || total_blocks < 1) return BPM_ERR_ARG;
+    hipLaunchKernelGGL(fold_bias_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, ndesc);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bpm_unfold_grads(const bpm_unfold_desc* table_dev, int ndesc, unsigned total_blocks, void* stream) {
+    if (!table_dev || ndesc < 1 || total_blocks < 1) return BPM_ERR_ARG;
+    hipLaunchKernelGGL(unfold_grads_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, ndesc);
+    BPM_CHECK_LAUNCH();
     return 0;
 }
 

@@ -33,7 +33,8 @@ import torch
 
 from . import ops
 from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,
-                   AttnProblem, CastProblem, EmbedProblem, GemmProblem, GmuProblem, LnProblem, PackDesc, PackProblem)
+                   AttnProblem, CastProblem, EmbedProblem, FoldDesc, GemmProblem, GmuProblem, LnProblem, PackDesc, PackProblem,
+                   UnfoldDesc)
 from .ops import pad32
 
 # dropout site ids (unique per encoder / layer / op; the seed changes per step)
@@ -113,6 +114,10 @@ class ParamStore:
         self._shadow_specs: List[Tuple[str, int, int, int, int, int, int, int]] = []
         self._shadow_off: Dict[str, int] = {}
         self._shadow_total = 0
+        self._fold_specs: List[tuple] = []
+        self._fold_off: Dict[str, int] = {}
+        self._fold_total = 0
+        self._fold_table = None
         self.shadow_flat: Optional[torch.Tensor] = None
         self._table = None
         self._master_ptr = self.master.data_ptr()
@@ -148,9 +153,11 @@ class ParamStore:
 
     # -- shadows --------------------------------------------------------------
     def add_shadow(self, key: str, name: str, rows: int, cols: int, *, src_col0: int = 0, src_ld: Optional[int] = None,
-                   dst_ld: Optional[int] = None, dst_col0: int = 0, base_key: Optional[str] = None) -> None:
-        """Register a CT shadow [rows, dst_ld] of master `name` viewed as [rows, src_ld][:, src_col0:src_col0+cols].
-        base_key: write into an already registered shadow (column block dst_col0) instead of a new one."""
+                   dst_ld: Optional[int] = None, dst_col0: int = 0, base_key: Optional[str] = None, src_row0: int = 0,
+                   colscale: Optional[str] = None) -> None:
+        """Register a CT shadow [rows, dst_ld] of master `name` viewed as [.., src_ld][src_row0:src_row0+rows,
+        src_col0:src_col0+cols].  base_key: write into an already registered shadow (column block dst_col0) instead
+        of a new one.  colscale: name of a [cols] parameter multiplied into the columns (LayerNorm gain folding)."""
         ld = pad32(cols)
         src_ld = cols if src_ld is None else src_ld
         dst_ld = ld if dst_ld is None else dst_ld
@@ -161,18 +168,29 @@ class ParamStore:
         else:
             off = self._shadow_off[base_key]
             self._shadow_off[key] = off + dst_col0
-        self._shadow_specs.append((name, rows, cols, ld, src_ld, dst_ld, src_col0, off + dst_col0))
+        self._shadow_specs.append((name, rows, cols, ld, src_ld, dst_ld, src_col0 + src_row0 * src_ld, off + dst_col0, colscale))
+
+    def add_fold(self, key: str, wname: str, row0: int, rows: int, cols: int, beta: str, bias: str, bias_off: int) -> None:
+        """Register a folded bias out[rows] = bias[bias_off:] + W[row0:row0+rows, :cols] . beta (fp32)."""
+        self._fold_off[key] = self._fold_total
+        self._fold_specs.append((wname, row0, rows, cols, beta, bias, bias_off, self._fold_total))
+        self._fold_total += (rows + 63) // 64 * 64
+
+    def fold(self, key: str, elem_off: int, n: int) -> torch.Tensor:
+        o = self._fold_off[key] + elem_off
+        return self.fold_flat[o:o + n]
 
     def finalize_shadows(self) -> None:
         ct = ops.ct_torch(self.dtype)
         self.shadow_flat = torch.zeros(max(self._shadow_total, 32), device=self.device, dtype=ct)
         esz = self.shadow_flat.element_size()
         descs, blk = [], 0
-        for (name, rows, cols, ld, src_ld, dst_ld, src_col0, off) in self._shadow_specs:
+        for (name, rows, cols, ld, src_ld, dst_ld, src_off, off, colscale) in self._shadow_specs:
             d = PackDesc()
-            d.src = self.params[name].data_ptr() + 4 * src_col0
+            d.src = self.params[name].data_ptr() + 4 * src_off
             d.dst = self.shadow_flat.data_ptr() + esz * off
             d.rows, d.cols, d.ld, d.src_ld, d.dst_ld, d.blk0 = rows, cols, ld, src_ld, dst_ld, blk
+            d.colscale = self.params[colscale].data_ptr() if colscale else None
             blk += (rows * ld + 1023) // 1024
             descs.append(d)
         self._ndesc, self._nblk = len(descs), blk
@@ -180,6 +198,21 @@ class ParamStore:
             arr = (PackDesc * len(descs))(*descs)
             raw = bytes(memoryview(arr))
             self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.fold_flat = torch.zeros(max(self._fold_total, 64), device=self.device, dtype=torch.float32)
+        fd, blk = [], 0
+        for (wname, row0, rows, cols, beta, bias, bias_off, off) in self._fold_specs:
+            w = self.params[wname]
+            ldw = w.shape[1]
+            f = FoldDesc()
+            f.W = w.data_ptr() + 4 * row0 * ldw
+            f.beta = self.params[beta].data_ptr()
+            f.b = self.params[bias].data_ptr() + 4 * bias_off
+            f.out = self.fold_flat.data_ptr() + 4 * off
+            f.rows, f.cols, f.ldw, f.blk0 = rows, cols, ldw, blk
+            blk += (rows + 3) // 4
+            fd.append(f)
+        self._nfold, self._fold_blk = len(fd), blk
+        self._fold_table = ops.device_table(fd) if fd else None
 
     def sptr(self, key: str, elem_off: int = 0) -> int:
         return self.shadow_flat.data_ptr() + self.shadow_flat.element_size() * (self._shadow_off[key] + elem_off)
@@ -187,6 +220,8 @@ class ParamStore:
     def refresh_shadows(self) -> None:
         if self._table is not None:
             ops.pack_weights(self.dtype, self._table, self._ndesc, self._nblk)
+        if self._fold_table is not None:
+            ops.fold_bias(self._fold_table, self._nfold, self._fold_blk)
 
 
 # ----------------------------------------------------------------------------
@@ -262,14 +297,19 @@ class EncoderGroupPlan:
             b["ke"], b["ve"] = z(Rk, d), z(Rk, d)
             b["out"] = z(e.T, B, d)
             b["stf"] = (z(R), z(R))
-            for nm, shape, dt in (("xn", (R, self.ld), ct), ("kn", (Rk, self.ld), ct), ("vn", (Rk, self.ld), ct),
+            # key / value source, normalised ONCE without affine (the per-layer LayerNorm gain and bias are folded
+            # into the K / V projection weights, see register_encoder_shadows)
+            b["khat"], b["vhat"] = z(Rk, self.ld, dt=ct), z(Rk, self.ld, dt=ct)
+            b["stk"], b["stv"] = (z(Rk), z(Rk)), (z(Rk), z(Rk))
+            b["Gk"], b["Gv"] = z(Rk, d), z(Rk, d)                   # sum over layers of d(khat), d(vhat)
+            b["dWf"] = [z(2 * d, d) for _ in range(L)]              # folded K/V weight gradients (per backward)
+            b["dbf"] = z(L, 2 * d)                                  # folded K/V bias gradients (column sums)
+            for nm, shape, dt in (("xn", (R, self.ld), ct),
                                   ("qh", (B, H, e.T, self.dhp), ct), ("kh", (B, H, e.S, self.dhp), ct),
                                   ("vh", (B, H, e.S, self.dhp), ct), ("ao", (R, self.ld), ct), ("lse", (B, H, e.T), torch.float32),
                                   ("xmid", (R, d), torch.float32), ("xn2", (R, self.ld), ct), ("h1", (R, self.ld4), ct),
                                   ("st0m", (R,), torch.float32), ("st0r", (R,), torch.float32),
-                                  ("st1m", (R,), torch.float32), ("st1r", (R,), torch.float32),
-                                  ("stkm", (Rk,), torch.float32), ("stkr", (Rk,), torch.float32),
-                                  ("stvm", (Rk,), torch.float32), ("stvr", (Rk,), torch.float32)):
+                                  ("st1m", (R,), torch.float32), ("st1r", (R,), torch.float32)):
                 b[nm] = [z(*shape, dt=dt) for _ in range(L)]
             if cfg.biprojection:
                 for nm, shape, dt in (("qs", (B, H, e.T, self.dhp), ct), ("ks", (B, H, e.T, self.dhp), ct),
@@ -292,10 +332,27 @@ class EncoderGroupPlan:
                 b["dy0"], b["dqs"], b["dks"], b["dvs"] = two(R, self.ld), two(R, self.ld), two(R, self.ld), two(R, self.ld)
             b["dao"] = z(B, H, e.T, self.dhp, dt=ct)
             b["delta"] = z(B, H, e.T)
-            b["dkn"], b["dvn"], b["dke"], b["dve"] = z(Rk, d), z(Rk, d), z(Rk, d), z(Rk, d)
+            b["dke"], b["dve"] = z(Rk, d), z(Rk, d)
             b["dxq"], b["dxk"], b["dxv"] = z(e.T, B, d), z(e.S, B, d), z(e.S, B, d)
             self.buf.append(b)
         self.table = sinusoid_table(max(max(e.T, e.S) for e in self.encs) + 1, d, dev)
+        self._ones, self._zeros = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+        # table of the launch that turns folded K/V gradients into in_proj / LayerNorm parameter gradients
+        lnK = 1 if cfg.biprojection else 0
+        ud, blk = [], 0
+        for e, b in zip(self.encs, self.buf):
+            for i in range(L):
+                pn = lambda leaf: self._pn(e, i, leaf)
+                u = UnfoldDesc()
+                u.dWf, u.dbf = b["dWf"][i].data_ptr(), b["dbf"][i].data_ptr()
+                u.W = store.p(pn("self_attn.in_proj_weight")).data_ptr() + 4 * d * d
+                u.gamma, u.beta = store.p(pn(f"layer_norms.{lnK}.weight")).data_ptr(), store.p(pn(f"layer_norms.{lnK}.bias")).data_ptr()
+                u.dW, u.dbias = store.gptr(pn("self_attn.in_proj_weight"), d * d), store.gptr(pn("self_attn.in_proj_bias"), d)
+                u.dgamma, u.dbeta = store.gptr(pn(f"layer_norms.{lnK}.weight")), store.gptr(pn(f"layer_norms.{lnK}.bias"))
+                u.rows, u.cols, u.ldw, u.blk0 = 2 * d, d, d, blk
+                blk += (2 * d + 15) // 16
+                ud.append(u)
+        self._unfold = (ops.device_table(ud), len(ud), blk)
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
         self._bwd = {True: self._build_bwd(True), False: self._build_bwd(False)}
 
@@ -318,11 +375,15 @@ class EncoderGroupPlan:
         c, st, B, d, H = self.cfg, self.store, self.B, self.cfg.d, self.cfg.H
         ld, ld4, dh, dhp = self.ld, self.ld4, self.dh, self.dhp
         pr = (lambda p: p) if training else (lambda p: 0.0)
-        steps, kv_steps = [], []
         A = ops.array
+        hat = []
+        for e, b in zip(self.encs, self.buf):
+            hat += [ops.ln_problem(b["ke"], self._ones, self._zeros, b["stk"][0], b["stk"][1], b["Rk"], out=b["khat"], ldo=ld),
+                    ops.ln_problem(b["ve"], self._ones, self._zeros, b["stv"][0], b["stv"][1], b["Rk"], out=b["vhat"], ldo=ld)]
+        steps, kv_steps = [], [(SIDE, (ops.ln_fwd, self.dtype, A(LnProblem, hat), d))]
         for i in range(c.layers):
             ln, qkv, att, outp, ln2, fc1, fc2 = [], [], [], [], [], [], []
-            lnkv, kvp = [], []
+            kvp = []
             pre = dict(ln=[], qkv=[], att=[], outp=[], cast=[])      # biprojection self-attention half
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -338,6 +399,12 @@ class EncoderGroupPlan:
                                             bias_n=ipb[which * d:(which + 1) * d], alpha=self.scale if which == 0 else 1.0,
                                             out_kind=OUT_HEADS, heads=(B, H, Tlen, dh, dhp))
 
+                def proj_kv(Ain, which, Cout):       # folded: khat (W_k * gamma)^T + (W_k beta + b_k)
+                    kvf = self._pn(e, i, KVF)
+                    return ops.gemm_problem(Ain, st.sptr(kvf, (which - 1) * d * ld), Cout, Rk, d, d, ld, ld, 0,
+                                            bias_n=st.fold(kvf, (which - 1) * d, d), out_kind=OUT_HEADS,
+                                            heads=(B, H, e.S, dh, dhp))
+
                 x_in = b["x"][i]
                 if c.biprojection:
                     g2, b2 = P("layer_norms.2.weight"), P("layer_norms.2.bias")
@@ -352,18 +419,16 @@ class EncoderGroupPlan:
                                                         drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
                     pre["cast"].append(ops.cast_problem(b["xmid0"][i], d, R, d, dst_ct=b["xq"][i], ldd=ld))
                     q_src, resid_src = b["xq"][i], b["xmid0"][i]
-                    gk, bk, gf, bf = g1, b1, g2, b2
+                    gf, bf = g2, b2
                     stf = (b["st2m"][i], b["st2r"][i])
                 else:
                     ln.append(ops.ln_problem(x_in, g0, b0, b["st0m"][i], b["st0r"][i], R, out=b["xn"][i], ldo=ld))
                     q_src, resid_src = b["xn"][i], x_in
-                    gk, bk, gf, bf = g0, b0, g1, b1
+                    gf, bf = g1, b1
                     stf = (b["st1m"][i], b["st1r"][i])
-                lnkv.append(ops.ln_problem(b["ke"], gk, bk, b["stkm"][i], b["stkr"][i], Rk, out=b["kn"][i], ldo=ld))
-                lnkv.append(ops.ln_problem(b["ve"], gk, bk, b["stvm"][i], b["stvr"][i], Rk, out=b["vn"][i], ldo=ld))
                 qkv.append(proj(q_src, R, 0, b["qh"][i], e.T))
-                kvp.append(proj(b["kn"][i], Rk, 1, b["kh"][i], e.S))
-                kvp.append(proj(b["vn"][i], Rk, 2, b["vh"][i], e.S))
+                kvp.append(proj_kv(b["khat"], 1, b["kh"][i]))
+                kvp.append(proj_kv(b["vhat"], 2, b["vh"][i]))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
                                             self._mask_off(e.T, e.S), drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
                 outp.append(ops.gemm_problem(b["ao"][i], st.sptr(wo), b["xmid"][i], R, d, d, ld, ld, d,
@@ -384,9 +449,7 @@ class EncoderGroupPlan:
                           (ops.rows_cast, self.dtype, A(CastProblem, pre["cast"]))]
             # K/V side of every layer depends only on the (embedded) key/value sources: the side stream runs it
             # ahead of the query chain; the main stream waits for layer i's K/V heads just before attention i.
-            kv_steps += [(SIDE, (ops.ln_fwd, self.dtype, A(LnProblem, lnkv), d)),
-                         (SIDE, self._gemm(GEMM_NT, kvp)),
-                         (MARK, i)]
+            kv_steps += [(SIDE, self._gemm(GEMM_NT, kvp)), (MARK, i)]
             if ln:
                 steps.append((ops.ln_fwd, self.dtype, A(LnProblem, ln), d))
             steps += [self._gemm(GEMM_NT, qkv),
@@ -412,6 +475,8 @@ class EncoderGroupPlan:
             fn(s[1], s[2], s[3])
         elif fn is ops.ln_bwd:
             fn(s[1], s[2], self.dtype, seed)
+        elif fn is ops.unfold_grads:
+            fn(s[1], s[2], s[3])
         else:
             raise RuntimeError("unknown step")
 
@@ -487,7 +552,7 @@ class EncoderGroupPlan:
         inv_relu = 1.0 / (1.0 - pr(c.relu_dropout))
         for i in reversed(range(c.layers)):
             wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], []
-            wg_att, dg_out, att, csum, dg_q, dg_kv, lnq, lnkv = [], [], [], [], [], [], [], []
+            wg_att, dg_out, att, csum, dg_q, dg_kv, lnq = [], [], [], [], [], [], []
             s_cast0, s_dgout0, s_att0, s_csum0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], [], []
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -530,11 +595,16 @@ class EncoderGroupPlan:
                                             dK=dk, lddk=ld, dV=dv, lddv=ld, dq_scale=self.scale,
                                             drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
                 ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
-                for w, src, rows in ((0, dq, R), (1, dk, Rk), (2, dv, Rk)):
-                    csum.append(ops.cast_problem(src, ld, rows, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
+                # query projection: gradients go straight to the parameters.  Key / value projections ran with the
+                # LayerNorm folded in: their bias column sums and weight gradients (against khat / vhat) land in
+                # per-layer scratch and are unfolded into in_proj / LayerNorm gradients by one launch at the end.
+                csum.append(ops.cast_problem(dq, ld, R, d, a_is_ct=True, colsum=st.gptr(ipb_g, 0)))
+                csum.append(ops.cast_problem(dk, ld, Rk, d, a_is_ct=True, colsum=b["dbf"][i][:d]))
+                csum.append(ops.cast_problem(dv, ld, Rk, d, a_is_ct=True, colsum=b["dbf"][i][d:]))
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
-                for w, dsrc, act, rows in ((0, dq, q_src, R), (1, dk, b["kn"][i], Rk), (2, dv, b["vn"][i], Rk)):
-                    wg_att.append(ops.gemm_problem(dsrc, act, st.gptr(ipw, w * d * d), d, d, rows, ld, ld, d, flags=F_ACCUM))
+                wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, R, ld, ld, d, flags=F_ACCUM))
+                wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ld, ld, d))
+                wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ld, ld, d))
                 if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
                     dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
                 else:
@@ -542,13 +612,9 @@ class EncoderGroupPlan:
                     lnq.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R, dy=b["dxn"],
                                               ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias"),
                                               **nxt))
-                dg_kv.append(ops.gemm_problem(dk, st.sptr(ipw, d * ld), b["dkn"], Rk, d, d, ld, ld, d))
-                dg_kv.append(ops.gemm_problem(dv, st.sptr(ipw, 2 * d * ld), b["dvn"], Rk, d, d, ld, ld, d))
-                gK, dgK, dbK = P(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.weight"), GP(f"layer_norms.{lnK}.bias")
-                lnkv.append(ops.ln_problem(b["ke"], gK, None, b["stkm"][i], b["stkr"][i], Rk, dy=b["dkn"], ldy=d, add=b["dke"],
-                                           dx=b["dke"], dgamma=dgK, dbeta=dbK))
-                lnkv.append(ops.ln_problem(b["ve"], gK, None, b["stvm"][i], b["stvr"][i], Rk, dy=b["dvn"], ldy=d, add=b["dve"],
-                                           dx=b["dve"], dgamma=dgK, dbeta=dbK))
+                kvf = self._pn(e, i, KVF)
+                dg_kv.append(ops.gemm_problem(dk, st.sptr(kvf, 0), b["Gk"], Rk, d, d, ld, ld, d, flags=F_ACCUM))
+                dg_kv.append(ops.gemm_problem(dv, st.sptr(kvf, d * ld), b["Gv"], Rk, d, d, ld, ld, d, flags=F_ACCUM))
                 if c.biprojection:
                     # ---- self-attention half (same attention parameters)
                     s_cast0.append(ops.cast_problem(dx, d, R, d, dst_ct=dy0, ldd=ld, colsum=GP("self_attn.out_proj.bias"),
@@ -585,7 +651,6 @@ class EncoderGroupPlan:
                       (SIDE, (ops.rows_cast, self.dtype, A(CastProblem, csum))),
                       (SIDE, self._gemm(GEMM_TN, wg_att)),
                       (SIDE, self._gemm(GEMM_NN, dg_kv)),
-                      (SIDE, (ops.ln_bwd, A(LnProblem, lnkv), d)),
                       self._gemm(GEMM_NN, dg_q)]
             if lnq:
                 steps.append((ops.ln_bwd, A(LnProblem, lnq), d))
@@ -600,7 +665,15 @@ class EncoderGroupPlan:
                           self._gemm(GEMM_NN, s_dg0c),
                           (ops.ln_bwd, A(LnProblem, s_ln0), d)]
             steps.append((MARK, i))
-        steps.append(JOIN)
+        # d(khat), d(vhat) summed over the layers -> d(embedded key / value source): LayerNorm backward without
+        # affine; then the folded K/V parameter gradients of every layer in one launch
+        hat = []
+        for e, b in zip(self.encs, self.buf):
+            hat += [ops.ln_problem(b["ke"], self._ones, None, b["stk"][0], b["stk"][1], b["Rk"], dy=b["Gk"], ldy=d, dx=b["dke"]),
+                    ops.ln_problem(b["ve"], self._ones, None, b["stv"][0], b["stv"][1], b["Rk"], dy=b["Gv"], ldy=d, dx=b["dve"])]
+        steps += [(SIDE, (ops.ln_bwd, A(LnProblem, hat), d)),
+                  (SIDE, (ops.unfold_grads,) + self._unfold),
+                  JOIN]
         return steps
 
     def backward(self, douts: Sequence[Optional[torch.Tensor]]):
@@ -612,8 +685,9 @@ class EncoderGroupPlan:
         fin, keep = [], []
         top = c.layers - 1
         for e, b, g in zip(self.encs, self.buf, douts):
-            b["dke"].zero_()
-            b["dve"].zero_()
+            b["Gk"].zero_()
+            b["Gv"].zero_()
+            b["dbf"].zero_()
             if g is None:
                 b["dx"].zero_()
                 b["dyf"][top % 3].zero_()
@@ -638,10 +712,18 @@ class EncoderGroupPlan:
         return [b["dxq"] for b in self.buf], [b["dxk"] for b in self.buf], [b["dxv"] for b in self.buf]
 
 
-def register_encoder_shadows(store: ParamStore, prefix: str, d: int, layers: int) -> None:
+KVF = "self_attn.in_proj_weight#kvf"      # key suffix of the folded key/value shadow and bias
+
+
+def register_encoder_shadows(store: ParamStore, prefix: str, d: int, layers: int, biprojection: bool = False) -> None:
+    lnK = 1 if biprojection else 0        # LayerNorm applied to the key / value source (transformer.py:167-172)
     for i in range(layers):
         p = f"{prefix}layers.{i}."
         store.add_shadow(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_weight", 3 * d, d)
+        # key / value projections with that LayerNorm folded in: W' = W * gamma (columns), b' = W beta + b
+        store.add_shadow(p + KVF, p + "self_attn.in_proj_weight", 2 * d, d, src_row0=d, colscale=p + f"layer_norms.{lnK}.weight")
+        store.add_fold(p + KVF, p + "self_attn.in_proj_weight", d, 2 * d, d, p + f"layer_norms.{lnK}.bias",
+                       p + "self_attn.in_proj_bias", d)
         store.add_shadow(p + "self_attn.out_proj.weight", p + "self_attn.out_proj.weight", d, d)
         store.add_shadow(p + "fc1.weight", p + "fc1.weight", 4 * d, d)
         store.add_shadow(p + "fc2.weight", p + "fc2.weight", d, 4 * d)

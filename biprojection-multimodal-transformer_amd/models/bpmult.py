@@ -492,7 +492,7 @@ class _BPMulTBase(nn.Module):
                 st.sections[sname] = (lo, hi)
             d = self.d
             for n in ENC_ORDER:
-                register_encoder_shadows(st, n + ".", d, self.layers)
+                register_encoder_shadows(st, n + ".", d, self.layers, biprojection=self.four_modal and n in LEVEL2)
             for k, od in (("l", self.orig_d_l), ("v", self.orig_d_v), ("a", self.orig_d_a)):
                 st.add_shadow(f"proj_{k}.weight", f"proj_{k}.weight", d, od)
             ld = pad32(d)

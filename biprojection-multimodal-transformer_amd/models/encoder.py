@@ -118,7 +118,7 @@ class TransformerEncoder(nn.Module):
         if self._store is None or not self._store.still_flat():
             dt = config.dtype_code(self.precision or config.precision())
             self._store = ParamStore(list(self.named_parameters()), dt)
-            register_encoder_shadows(self._store, "", self.embed_dim, len(self.layers))
+            register_encoder_shadows(self._store, "", self.embed_dim, len(self.layers), biprojection=self.biprojection)
             self._store.finalize_shadows()
             self._plans = {}
             self._anchor = torch.zeros(1, device=self._store.device, requires_grad=True)

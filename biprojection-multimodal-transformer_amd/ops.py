@@ -145,6 +145,20 @@ def pack_weights(dtype, table_dev: torch.Tensor, ndesc: int, total_blocks: int) 
     _lib.check(_lib.lib().bpm_pack_weights(dtype, table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_pack_weights")
 
 
+def device_table(descs) -> torch.Tensor:
+    """ctypes descriptor structs -> one device-resident byte tensor (the table-driven launches read it on the GPU)."""
+    arr = (type(descs[0]) * len(descs))(*descs)
+    return torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8).to("cuda")
+
+
+def fold_bias(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:
+    _lib.check(_lib.lib().bpm_fold_bias(table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_fold_bias")
+
+
+def unfold_grads(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:
+    _lib.check(_lib.lib().bpm_unfold_grads(table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_unfold_grads")
+
+
 def embed_problem(x, out, T, B, *, accumulate=False, drop_p=0.0, drop_site=0) -> EmbedProblem:
     p = EmbedProblem()
     p.x, p.out, p.T, p.B = _f32(x, "embed.x"), _f32(out, "embed.out"), T, B

@@ -135,14 +135,40 @@ int bpm_pack_rows_bwd(const bpm_pack_problem* probs, int n, uint64_t seed, void*
 
 /* fp32 master weights -> CT shadows with zero-padded leading dimension; the
  * descriptor table lives in DEVICE memory (built once, reused every step).
- * Row r: dst[r*dst_ld + c] = c < cols ? src[r*src_ld + c] : 0 for c < ld. */
+ * Row r: dst[r*dst_ld + c] = c < cols ? src[r*src_ld + c] * (colscale ? colscale[c] : 1) : 0 for c < ld.
+ * colscale (fp32 [cols], device) folds a LayerNorm gain into the projection that follows it: the key / value
+ * side of a crossmodal layer normalises the SAME embedded source in every layer (transformer.py:167-172), so
+ * the engine normalises it once without affine and uses W' = W * gamma, b' = W beta + b per layer. */
 typedef struct bpm_pack_desc {
     const void* src;
     void* dst;
     int rows, cols, ld, src_ld, dst_ld;
     unsigned blk0;          /* first block of this tensor; a block covers 1024 (row, c<ld) elements */
+    const float* colscale;
 } bpm_pack_desc;
 int bpm_pack_weights(int dtype, const bpm_pack_desc* table_dev, int ndesc, unsigned total_blocks, void* stream);
+
+/* Folded bias of the above: out[n] = b[n] + sum_c W[n*ldw + c] * beta[c], n < rows.  Device-resident table;
+ * one wave per output row, 4 rows per block (blk0 = first block of the entry). */
+typedef struct bpm_fold_desc {
+    const float* W; const float* beta; const float* b; float* out;
+    int rows, cols, ldw;
+    unsigned blk0;
+} bpm_fold_desc;
+int bpm_fold_bias(const bpm_fold_desc* table_dev, int ndesc, unsigned total_blocks, void* stream);
+
+/* Backward of the folding.  The weight-gradient GEMM against the un-affined normalised source gives
+ * dWf = dY^T xhat and the bias column sums give dbf; this turns them into the gradients of the real parameters:
+ *   dW[n,c] += dWf[n,c]*gamma[c] + dbf[n]*beta[c];   dbias[n] += dbf[n];
+ *   dgamma[c] += sum_n dWf[n,c]*W[n,c];               dbeta[c] += sum_n dbf[n]*W[n,c]      (atomics per block)
+ * dWf is dense [rows, cols]; W / dW have row stride ldw.  16 rows per block. */
+typedef struct bpm_unfold_desc {
+    const float* dWf; const float* dbf; const float* W; const float* gamma; const float* beta;
+    float* dW; float* dbias; float* dgamma; float* dbeta;
+    int rows, cols, ldw;
+    unsigned blk0;
+} bpm_unfold_desc;
+int bpm_unfold_grads(const bpm_unfold_desc* table_dev, int ndesc, unsigned total_blocks, void* stream);
 
 /* Encoder prologue.  Replaces embed_scale * x + embed_positions(x[:,:,0]) and
  * F.dropout (transformer.py:66-79; position_embedding.py:8-27,62-76):
