@@ -319,6 +319,170 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const Grp<LnP> grp, int d) {
 }
 
 // ---------------------------------------------------------------------------
+// Vector forms (d % 4 == 0, 16-byte aligned rows): a lane owns 4-column chunks lane, lane+64, ... (NV of them),
+// moved as one 16-byte (f32) / 8-byte (bf16) access each; the backward keeps TWO rows in flight per wave.
+// ---------------------------------------------------------------------------
+template <typename CT>
+BPM_DEV void put4(void* p, size_t i, f32x4 v) {
+    if constexpr (sizeof(CT) == 4) *(f32x4*)((float*)p + i) = v;
+    else { bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3]; *(bf16x4*)((bf16_t*)p + i) = o; }
+}
+BPM_DEV float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+template <typename CT, int NV>
+__global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const Grp<LnP> grp, int d, float eps) {
+    unsigned bid = blockIdx.x, nblk;
+    const LnP& P = pick(grp, bid, nblk);
+    const int lane = threadIdx.x & 63;
+    const int wpb = NT / 64;
+    const int nch = d >> 2;
+    f32x4 gam[NV], bet[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        const int q = lane + 64 * e;
+        const bool in = q < nch;
+        gam[e] = *(const f32x4*)(P.gamma + 4 * (in ? q : 0));
+        bet[e] = *(const f32x4*)(P.beta + 4 * (in ? q : 0));
+    }
+    const float inv_d = 1.f / d;
+    for (int row = bid * wpb + (threadIdx.x >> 6); row < P.R; row += nblk * wpb) {
+        const float* xr = P.x + (size_t)row * d;
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const int q = lane + 64 * e;
+            const f32x4 t = *(const f32x4*)(xr + 4 * (q < nch ? q : 0));
+            v[e] = q < nch ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            s += sum4(v[e]);
+        }
+        const float mu = wave_sum(s) * inv_d;
+        float qq = 0.f;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const int q = lane + 64 * e;
+            f32x4 t = v[e] - mu;
+            if (q >= nch) t = f32x4{0.f, 0.f, 0.f, 0.f};
+            v[e] = t;
+            qq += sum4(t * t);
+        }
+        const float rs = rsqrtf(wave_sum(qq) * inv_d + eps);
+        if (lane == 0) { P.mean[row] = mu; P.rstd[row] = rs; }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const int q = lane + 64 * e;
+            if (q < nch) {
+                const f32x4 y = v[e] * rs * gam[e] + bet[e];
+                if (P.out_f32) *(f32x4*)((float*)P.out + (size_t)row * P.ldo + 4 * q) = y;
+                else put4<CT>(P.out, (size_t)row * P.ldo + 4 * q, y);
+            } else if (!P.out_f32 && 4 * q < P.ldo) {
+                put4<CT>(P.out, (size_t)row * P.ldo + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+    }
+}
+
+template <typename CT, int NV>
+__global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int d) {
+    __shared__ float red[3][NT / 64][NV * 256];
+    unsigned bid = blockIdx.x, nblk;
+    const LnP& P = pick(grp, bid, nblk);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wpb = NT / 64;
+    const int nch = d >> 2;
+    const bool fused = P.cast != nullptr;          // uniform per block
+    const bool has_add = P.add != nullptr;
+    const float inv_d = 1.f / d;
+    f32x4 gam[NV], ag[NV], ab[NV], ac[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        const int q = lane + 64 * e;
+        gam[e] = *(const f32x4*)(P.gamma + 4 * (q < nch ? q : 0));
+        ag[e] = ab[e] = ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int U = 2;                             // rows in flight per wave
+    for (int row0 = (bid * wpb + wv) * U; row0 < P.R; row0 += nblk * wpb * U) {
+        f32x4 xv[U][NV], gv[U][NV], av[U][NV];
+        float mu[U], rs[U];
+        // phase 1: every load of the U rows (clamped rows / chunks, zeroed by selects)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + u;
+            const int rc = row < P.R ? row : row0;
+            mu[u] = P.mean[rc]; rs[u] = P.rstd[rc];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                const int q = lane + 64 * e;
+                const int qc = q < nch ? q : 0;
+                xv[u][e] = *(const f32x4*)(P.x + (size_t)rc * d + 4 * qc);
+                gv[u][e] = *(const f32x4*)(P.dy + (size_t)rc * P.ldy + 4 * qc);
+                av[u][e] = has_add ? *(const f32x4*)(P.add + (size_t)rc * d + 4 * qc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + u;
+            const bool rok = row < P.R;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                const int q = lane + 64 * e;
+                const bool ok = rok && q < nch;
+                const f32x4 dyv = ok ? gv[u][e] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 xh = ok ? (xv[u][e] - mu[u]) * rs[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 g = dyv * gam[e];
+                ag[e] += dyv * xh;
+                ab[e] += dyv;
+                s1 += sum4(g);
+                s2 += sum4(g * xh);
+                xv[u][e] = xh; gv[u][e] = g;
+            }
+            s1 = wave_sum(s1) * inv_d;
+            s2 = wave_sum(s2) * inv_d;
+            if (!rok) continue;                      // wave-uniform
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                const int q = lane + 64 * e;
+                if (q < nch) {
+                    const f32x4 v = av[u][e] + rs[u] * (gv[u][e] - s1 - xv[u][e] * s2);
+                    *(f32x4*)(P.dx + (size_t)row * d + 4 * q) = v;
+                    if (fused) {
+                        f32x4 m = v;
+                        if (P.drop.thresh != 0) {   // row*d + 4q is even: two hash pairs
+                            float d0, d1, d2, d3;
+                            const uint32_t i0 = (uint32_t)row * (uint32_t)d + 4u * (uint32_t)q;
+                            bpm_drop_mult2(P.drop, i0, d0, d1);
+                            bpm_drop_mult2(P.drop, i0 + 2u, d2, d3);
+                            m[0] *= d0; m[1] *= d1; m[2] *= d2; m[3] *= d3;
+                        }
+                        put4<CT>(P.cast, (size_t)row * P.ldc + 4 * q, m);
+                        ac[e] += m;
+                    }
+                } else if (fused && 4 * q < P.ldc) {
+                    put4<CT>(P.cast, (size_t)row * P.ldc + 4 * q, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+            }
+        }
+    }
+    const bool want_g = P.dgamma != nullptr, want_c = fused && P.csum != nullptr;
+    if (!want_g && !want_c) return;                  // uniform per block
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        *(f32x4*)(&red[0][wv][4 * (lane + 64 * e)]) = ag[e];
+        *(f32x4*)(&red[1][wv][4 * (lane + 64 * e)]) = ab[e];
+        *(f32x4*)(&red[2][wv][4 * (lane + 64 * e)]) = ac[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += NT) {
+        float sg = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; sc += red[2][w][c]; }
+        if (want_g) { atomicAdd(P.dgamma + c, sg); atomicAdd(P.dbeta + c, sb); }
+        if (want_c) atomicAdd(P.csum + c, sc);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // rows_cast: y = (a [+ b]) * drop_mult ; a is fp32 or CT; written as CT
 // (padded) and/or fp32; optional column sums (bias gradient) by atomics.
 // Block = 32 rows x 256 columns.
@@ -574,12 +738,42 @@ static int fill_ln(Grp<LnP>& g, const bpm_ln_problem* q, int n, int d, bool bwd,
     return 0;
 }
 
+// vector kernels: d % 4 == 0, every row 16-byte (CT outputs: 8-byte) aligned
+static bool ln_vec_ok(const bpm_ln_problem* q, int n, int d, bool bwd, int ct_size) {
+    if (d % 4 || d > 4 * 64 * 4) return false;
+    for (int i = 0; i < n; ++i) {
+        const bpm_ln_problem& s = q[i];
+        uintptr_t a = (uintptr_t)s.x | (uintptr_t)s.gamma;
+        if (bwd) {
+            a |= (uintptr_t)s.dy | (uintptr_t)s.add | (uintptr_t)s.dx;
+            if (s.ldy % 4) return false;
+            if (s.cast && (((uintptr_t)s.cast % (4 * ct_size)) || s.ldc % 4)) return false;
+        } else {
+            a |= (uintptr_t)s.beta;
+            if (s.ldo % 4 || ((uintptr_t)s.out % (4 * (s.out_f32 ? 4 : ct_size)))) return false;
+        }
+        if (a & 15) return false;
+    }
+    return true;
+}
+
 extern "C" int bpm_ln_fwd(int dtype, const bpm_ln_problem* q, int n, int d, float eps, void* stream) {
     Grp<LnP> g;
     int span;
     int rc = fill_ln(g, q, n, d, false, &span);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (ln_vec_ok(q, n, d, false, dtype == BPM_BF16 ? 2 : 4) && span <= 4 * 64 * 4) {
+#define BPM_LN_FWDV(NV)                                                                                        \
+        if (span <= 256 * NV) {                                                                                \
+            if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_fwd_vec_kernel<bf16_t, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, eps); \
+            else hipLaunchKernelGGL((ln_fwd_vec_kernel<float, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, eps);                   \
+            BPM_CHECK_LAUNCH();                                                                                \
+            return 0;                                                                                          \
+        }
+        BPM_LN_FWDV(1) BPM_LN_FWDV(2) BPM_LN_FWDV(3) BPM_LN_FWDV(4)
+#undef BPM_LN_FWDV
+    }
 #define BPM_LN_FWD(NE)                                                                            \
     if (span <= 64 * NE) {                                                                        \
         if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NE>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, eps); \
@@ -599,6 +793,21 @@ extern "C" int bpm_ln_bwd(int dtype, const bpm_ln_problem* q, int n, int d, uint
     int rc = fill_ln(g, q, n, d, true, &span, seed);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (ln_vec_ok(q, n, d, true, dtype == BPM_BF16 ? 2 : 4)) {
+        // two rows per wave and iteration: half the blocks of the scalar kernel (and half its atomics)
+        for (int i = 0; i < n; ++i) g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)q[i].R, 8, 128);
+        int maxw = d;
+        for (int i = 0; i < n; ++i) if (q[i].cast && q[i].ldc > maxw) maxw = q[i].ldc;
+#define BPM_LN_BWDV(NV)                                                                                        \
+        if (maxw <= 256 * NV) {                                                                                \
+            if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d); \
+            else hipLaunchKernelGGL((ln_bwd_vec_kernel<float, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d);                   \
+            BPM_CHECK_LAUNCH();                                                                                \
+            return 0;                                                                                          \
+        }
+        BPM_LN_BWDV(1) BPM_LN_BWDV(2) BPM_LN_BWDV(3) BPM_LN_BWDV(4)
+#undef BPM_LN_BWDV
+    }
 #define BPM_LN_BWD(NE)                                                                                               \
     if (d <= 64 * NE) {                                                                                              \
         if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NE>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d); \
