@@ -17,6 +17,11 @@ namespace {
 constexpr int NT = 256;
 
 template <typename CT> BPM_DEV void put(void* p, size_t i, float v) { ((CT*)p)[i] = Tr<CT>::from_f(v); }
+template <typename CT>
+BPM_DEV void put4(void* p, size_t i, f32x4 v) {
+    if constexpr (sizeof(CT) == 4) *(f32x4*)((float*)p + i) = v;
+    else { bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3]; *(bf16x4*)((bf16_t*)p + i) = o; }
+}
 
 inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) { return bpm_make_drop(p, seed, site); }
 
@@ -98,20 +103,35 @@ __global__ void pack_weights_kernel(const bpm_pack_desc* __restrict__ tab, int n
     const bpm_pack_desc d = tab[lo];
     const size_t total = (size_t)d.rows * d.ld;
     const size_t i0 = ((size_t)(bid - d.blk0) * NT + threadIdx.x) * 4;
+    if (i0 >= total) return;
     const float* src = (const float*)d.src;
+    // ld % 4 == 0: the thread's 4 elements share a row
+    const size_t r = i0 / d.ld;
+    const int c = (int)(i0 - r * d.ld);
+    const float* sp = src + r * d.src_ld + c;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((d.ld & 3) == 0 && c + 3 < d.cols && (((uintptr_t)sp) & 15) == 0) {
+        v = *(const f32x4*)sp;
+        if (d.colscale) v *= *(const f32x4*)(d.colscale + c);     // colscale is 64-byte aligned and c % 4 == 0
+        if ((((uintptr_t)d.dst) & 15) == 0 && (d.dst_ld & 3) == 0) { put4<CT>(d.dst, r * d.dst_ld + c, v); return; }
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const size_t i = i0 + e;
-        if (i >= total) break;
-        const int c = (int)(i % d.ld);
-        const size_t r = i / d.ld;
-        float v = 0.f;
-        if (c < d.cols) {
-            v = src[r * d.src_ld + c];
-            if (d.colscale) v *= d.colscale[c];
+        for (int e = 0; e < 4; ++e) {
+            const size_t i = i0 + e;
+            if (i >= total) break;
+            const int ce = (int)(i % d.ld);
+            const size_t re = i / d.ld;
+            float x = 0.f;
+            if (ce < d.cols) {
+                x = src[re * d.src_ld + ce];
+                if (d.colscale) x *= d.colscale[ce];
+            }
+            put<CT>(d.dst, re * d.dst_ld + ce, x);
         }
-        put<CT>(d.dst, r * d.dst_ld + c, v);
+        return;
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) put<CT>(d.dst, r * d.dst_ld + c + e, v[e]);
 }
 
 template <typename D>
@@ -322,11 +342,6 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const Grp<LnP> grp, int d) {
 // Vector forms (d % 4 == 0, 16-byte aligned rows): a lane owns 4-column chunks lane, lane+64, ... (NV of them),
 // moved as one 16-byte (f32) / 8-byte (bf16) access each; the backward keeps TWO rows in flight per wave.
 // ---------------------------------------------------------------------------
-template <typename CT>
-BPM_DEV void put4(void* p, size_t i, f32x4 v) {
-    if constexpr (sizeof(CT) == 4) *(f32x4*)((float*)p + i) = v;
-    else { bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3]; *(bf16x4*)((bf16_t*)p + i) = o; }
-}
 BPM_DEV float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 template <typename CT, int NV>
