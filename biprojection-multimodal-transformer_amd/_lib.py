@@ -132,6 +132,8 @@ SIGNATURES = {
     "bpm_gemm_grouped": [_I, _I, C.POINTER(GemmProblem), _I, _U64, _P],
     "bpm_attn_fwd": [_I, C.POINTER(AttnProblem), _I, _U64, _P],
     "bpm_attn_bwd": [_I, C.POINTER(AttnProblem), _I, _U64, _P],
+    "bpm_attn_bwd_dq": [_I, C.POINTER(AttnProblem), _I, _U64, _P],
+    "bpm_attn_bwd_dkv": [_I, C.POINTER(AttnProblem), _I, _U64, _P],
     "bpm_pack_rows_fwd": [_I, C.POINTER(PackProblem), _I, _U64, _P],
     "bpm_pack_rows_bwd": [C.POINTER(PackProblem), _I, _U64, _P],
     "bpm_pack_weights": [_I, _P, _I, C.c_uint, _P],

@@ -570,25 +570,41 @@ extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob,
 }
 
 // dQ first (it also produces delta), then dK/dV on the same stream.
-extern "C" int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
+// parts: 1 = dQ (+ delta), 2 = dK/dV (reads the delta a dQ pass wrote), 3 = both in that order
+static int attn_bwd_parts(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream, int parts) {
     AGroup g;
     int total = 0;
     int rc = fill(g, probs, nprob, 0, seed, &total);
     if (rc) return rc;
     for (int i = 0; i < nprob; ++i) {
         const bpm_attn_problem& q = probs[i];
-        if (!q.Q || !q.K || !q.V || !q.O || !q.lse || !q.dO || !q.delta || !q.dQ || !q.dK || !q.dV) return BPM_ERR_ARG;
+        if (!q.Q || !q.K || !q.V || !q.O || !q.lse || !q.dO || !q.delta) return BPM_ERR_ARG;
+        if ((parts & 1) && !q.dQ) return BPM_ERR_ARG;
+        if ((parts & 2) && (!q.dK || !q.dV)) return BPM_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    // algorithmic backward = dP, dQ (here) + dV, dK (next kernel): 4 * pairs * dh each; recomputing S is overhead
+    // algorithmic backward = dP, dQ (first kernel) + dV, dK (second): 4 * pairs * dh each; recomputing S is overhead
     const double w = 4.0 * useful_pair_flops(probs, nprob);
-    {
+    if (parts & 1) {
         BpmProfScope prof(BPM_K_ATTN_BWD_DQ, s, w);
         rc = dtype == BPM_BF16 ? dispatch<bf16_t>(1, probs[0].dhp, g, total, s) : dispatch<float>(1, probs[0].dhp, g, total, s);
+        if (rc) return rc;
     }
-    if (rc) return rc;
-    rc = fill(g, probs, nprob, 1, seed, &total);
-    if (rc) return rc;
-    BpmProfScope prof(BPM_K_ATTN_BWD_DKV, s, w);
-    return dtype == BPM_BF16 ? dispatch<bf16_t>(2, probs[0].dhp, g, total, s) : dispatch<float>(2, probs[0].dhp, g, total, s);
+    if (parts & 2) {
+        rc = fill(g, probs, nprob, 1, seed, &total);
+        if (rc) return rc;
+        BpmProfScope prof(BPM_K_ATTN_BWD_DKV, s, w);
+        rc = dtype == BPM_BF16 ? dispatch<bf16_t>(2, probs[0].dhp, g, total, s) : dispatch<float>(2, probs[0].dhp, g, total, s);
+    }
+    return rc;
+}
+
+extern "C" int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
+    return attn_bwd_parts(dtype, probs, nprob, seed, stream, 3);
+}
+extern "C" int bpm_attn_bwd_dq(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
+    return attn_bwd_parts(dtype, probs, nprob, seed, stream, 1);
+}
+extern "C" int bpm_attn_bwd_dkv(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
+    return attn_bwd_parts(dtype, probs, nprob, seed, stream, 2);
 }

@@ -256,6 +256,7 @@ def _splitk(tiles_total: int, k: int) -> int:
 
 SIDE, JOIN, MARK, WAIT = "side", "join", "mark", "wait"
 _SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
+_DKV_SIDE = os.environ.get("BPMULT_DKV_SIDE", "0") == "1"
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -330,8 +331,11 @@ class EncoderGroupPlan:
             b["dq"], b["dk"], b["dv"] = two(R, self.ld), two(Rk, self.ld), two(Rk, self.ld)
             if cfg.biprojection:
                 b["dy0"], b["dqs"], b["dks"], b["dvs"] = two(R, self.ld), two(R, self.ld), two(R, self.ld), two(R, self.ld)
-            b["dao"] = z(B, H, e.T, self.dhp, dt=ct)
-            b["delta"] = z(B, H, e.T)
+            # read by the side-stream dK/dV pass of the cross attention: by layer parity like dq/dk/dv
+            b["dao"] = [z(B, H, e.T, self.dhp, dt=ct) for _ in range(2)]
+            b["delta"] = [z(B, H, e.T) for _ in range(2)]
+            if cfg.biprojection:
+                b["dao0"], b["delta0"] = z(B, H, e.T, self.dhp, dt=ct), z(B, H, e.T)
             b["dke"], b["dve"] = z(Rk, d), z(Rk, d)
             b["dxq"], b["dxk"], b["dxv"] = z(e.T, B, d), z(e.S, B, d), z(e.S, B, d)
             self.buf.append(b)
@@ -469,7 +473,7 @@ class EncoderGroupPlan:
         fn = s[0]
         if fn is ops.gemm_grouped:
             fn(s[1], s[2], s[3], seed)
-        elif fn in (ops.attn_fwd, ops.attn_bwd, ops.rows_cast):
+        elif fn in (ops.attn_fwd, ops.attn_bwd, ops.attn_bwd_dq, ops.attn_bwd_dkv, ops.rows_cast):
             fn(s[1], s[2], seed)
         elif fn is ops.ln_fwd:
             fn(s[1], s[2], s[3])
@@ -565,7 +569,7 @@ class EncoderGroupPlan:
                 stF = (b["st2m"][i], b["st2r"][i]) if c.biprojection else (b["st1m"][i], b["st1r"][i])
                 dx = b["dx"]
                 par = i & 1
-                dh1, dy, dq, dk, dv = (b[n][par] for n in ("dh1", "dy", "dq", "dk", "dv"))
+                dh1, dy, dq, dk, dv, dao, delta = (b[n][par] for n in ("dh1", "dy", "dq", "dk", "dv", "dao", "delta"))
                 dyf = b["dyf"][i % 3]
                 # hand-off to the next layer down (i-1): its FFN-output gradient dyf = dropmask(dx) and fc2.bias
                 # gradient are produced by whichever LayerNorm backward finishes this layer's dx
@@ -588,10 +592,10 @@ class EncoderGroupPlan:
                 # ---- (cross) attention block
                 wg_att.append(ops.gemm_problem(dy, b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
                                                flags=F_ACCUM))
-                dg_out.append(ops.gemm_problem(dy, st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                dg_out.append(ops.gemm_problem(dy, st.sptr(wo), dao, R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                heads=(B, H, e.T, dh, dhp)))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
-                                            self._mask_off(e.T, e.S), dO=b["dao"], delta=b["delta"], dQ=dq, lddq=ld,
+                                            self._mask_off(e.T, e.S), dO=dao, delta=delta, dQ=dq, lddq=ld,
                                             dK=dk, lddk=ld, dV=dv, lddv=ld, dq_scale=self.scale,
                                             drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
                 ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
@@ -621,10 +625,10 @@ class EncoderGroupPlan:
                                                     drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
                     s_wg0.append(ops.gemm_problem(dy0, b["aos"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
                                                   flags=F_ACCUM))
-                    s_dgout0.append(ops.gemm_problem(dy0, st.sptr(wo), b["dao"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                    s_dgout0.append(ops.gemm_problem(dy0, st.sptr(wo), b["dao0"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                      heads=(B, H, e.T, dh, dhp)))
                     s_att0.append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H, e.T, e.T,
-                                                   dh, dhp, self._mask_off(e.T, e.T), dO=b["dao"], delta=b["delta"], dQ=dqs,
+                                                   dh, dhp, self._mask_off(e.T, e.T), dO=b["dao0"], delta=b["delta0"], dQ=dqs,
                                                    lddq=ld, dK=dks, lddk=ld, dV=dvs, lddv=ld, dq_scale=self.scale,
                                                    drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
                     for w, src in ((0, dqs), (1, dks), (2, dvs)):
@@ -647,7 +651,11 @@ class EncoderGroupPlan:
                       self._gemm(GEMM_NN, dg_fc1),
                       (ops.ln_bwd, A(LnProblem, lnf), d),
                       self._gemm(GEMM_NN, dg_out),
-                      (ops.attn_bwd, self.dtype, A(AttnProblem, att)),
+                      (ops.attn_bwd_dq, self.dtype, A(AttnProblem, att)),
+                      # dK / dV feed only side work, but running their pass beside the main chain measured SLOWER
+                      # (17.7 -> 18.7 ms/step: the side stream becomes the longer one); opt-in for experiments
+                      ((SIDE, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))) if _DKV_SIDE
+                       else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
                       (SIDE, (ops.rows_cast, self.dtype, A(CastProblem, csum))),
                       (SIDE, self._gemm(GEMM_TN, wg_att)),
                       (SIDE, self._gemm(GEMM_NN, dg_kv)),

@@ -119,6 +119,20 @@ def attn_bwd(dtype: int, probs, seed: int = 0) -> None:
         _lib.check(L.bpm_attn_bwd(dtype, sub, k, seed, s), "bpm_attn_bwd")
 
 
+def attn_bwd_dq(dtype: int, probs, seed: int = 0) -> None:
+    arr = _as_array(AttnProblem, probs)
+    L, s = _lib.lib(), _stream()
+    for sub, k in _chunks(arr, AttnProblem, None):
+        _lib.check(L.bpm_attn_bwd_dq(dtype, sub, k, seed, s), "bpm_attn_bwd_dq")
+
+
+def attn_bwd_dkv(dtype: int, probs, seed: int = 0) -> None:
+    arr = _as_array(AttnProblem, probs)
+    L, s = _lib.lib(), _stream()
+    for sub, k in _chunks(arr, AttnProblem, None):
+        _lib.check(L.bpm_attn_bwd_dkv(dtype, sub, k, seed, s), "bpm_attn_bwd_dkv")
+
+
 # ----------------------------------------------------------------------------
 # row kernels
 # ----------------------------------------------------------------------------

@@ -114,6 +114,11 @@ typedef struct bpm_attn_problem {
 
 int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
 int bpm_attn_bwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
+/* The two halves of bpm_attn_bwd as separate launches: _dq writes dQ and delta = rowsum(dO * O); _dkv reads that
+ * delta and writes dK, dV.  Only dQ is on the backward critical path (dK / dV feed weight gradients and the
+ * key/value-source gradient), so the engine runs _dkv on its side stream. */
+int bpm_attn_bwd_dq(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
+int bpm_attn_bwd_dkv(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------
  * Row kernels.  All are grouped: `n` problems (<= BPM_MAX_GROUP) per launch,
