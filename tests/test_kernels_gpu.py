@@ -332,3 +332,126 @@ def test_rows_cast_and_gmu(dtype):
         assert (got[:, d:].float() == 0).all()
     close(dx1, x1.grad, 1e-5, "dx1")
     close(dx2, x2.grad, 1e-5, "dx2")
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("variant", [GEMM_NT, GEMM_NN, GEMM_TN])
+def test_gemm_hardware_bounded_loader(dtype, variant):
+    """BPM_GEMM_KPAD_ZERO (buffer loads, no k-tail masking) == the masked loader, on ragged M / N / K with
+    zero-padded rows, grouped with a second problem of another size."""
+    from bpmult_amd.ops import F_KPAD
+    outs = {}
+    for flag in (0, F_KPAD):
+        probs, keep, refs = [], [], []
+        for (M, N, K, s0) in ((203, 77, 300, 60), (64, 300, 45, 70)):
+            if variant == GEMM_NT:
+                A, Ar = to_ct(rnd(M, K, seed=s0), dtype)
+                Bm, Br = to_ct(rnd(N, K, seed=s0 + 1, scale=K ** -0.5), dtype)
+                ref = Ar.double() @ Br.double().T
+            elif variant == GEMM_NN:
+                A, Ar = to_ct(rnd(M, K, seed=s0), dtype)
+                Bm, Br = to_ct(rnd(K, N, seed=s0 + 1, scale=K ** -0.5), dtype)
+                ref = Ar.double() @ Br.double()
+            else:
+                A, Ar = to_ct(rnd(K, M, seed=s0), dtype)
+                Bm, Br = to_ct(rnd(K, N, seed=s0 + 1, scale=K ** -0.5), dtype)
+                ref = Ar.double().T @ Br.double()
+            out = torch.full((M, N), float("nan"), device=DEV)
+            keep += [A, Bm, out]
+            refs.append(ref)
+            probs.append(ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N, flags=flag))
+        ops.gemm_grouped(dtype, variant, probs)
+        outs[flag] = [keep[2].cpu(), keep[5].cpu()]
+        for o, r in zip(outs[flag], refs):
+            close(o, r, tol(dtype) if dtype == BPM_F32 else 2e-3, f"gemm variant {variant} flag {flag}")
+    for a, b in zip(outs[0], outs[F_KPAD]):
+        assert torch.equal(a, b), "the two loaders must agree bit for bit"
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_kv_layernorm_folding(dtype):
+    """pack_weights(colscale) + fold_bias + unfold_grads reproduce y = LN(x; gamma, beta) W^T + b and its gradients
+    from the un-affined normalised source (the engine's key / value path)."""
+    import ctypes as C
+    from bpmult_amd._lib import FoldDesc, PackDesc, UnfoldDesc
+    R, d, n = 50, 300, 2 * 300
+    ld = pad32(d)
+    x = rnd(R, d, seed=81) * 1.5 + 0.2
+    W = (rnd(n, d, seed=82) * d ** -0.5).requires_grad_(True)
+    b = (0.1 * rnd(n, seed=83)).requires_grad_(True)
+    gamma = (1 + 0.2 * rnd(d, seed=84)).requires_grad_(True)
+    beta = (0.2 * rnd(d, seed=85)).requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5) @ W.T + b
+    dy = rnd(R, n, seed=86)
+    (y * dy).sum().backward()
+    xhat = torch.nn.functional.layer_norm(x, (d,))
+
+    Wd, bd, gd, btd = (t.detach().to(DEV).contiguous() for t in (W, b, gamma, beta))
+    shadow = torch.full((n, ld), float("nan"), device=DEV).to(ops.ct_torch(dtype))
+    pd = PackDesc()
+    pd.src, pd.dst, pd.rows, pd.cols, pd.ld, pd.src_ld, pd.dst_ld, pd.blk0 = Wd.data_ptr(), shadow.data_ptr(), n, d, ld, d, ld, 0
+    pd.colscale = gd.data_ptr()
+    ops.pack_weights(dtype, ops.device_table([pd]), 1, (n * ld + 1023) // 1024)
+    close(shadow[:, :d].float(), (W * gamma).detach(), 1e-6 if dtype == BPM_F32 else 1e-2, "folded weight")
+    assert (shadow[:, d:].float() == 0).all()
+
+    bf = torch.empty(n, device=DEV)
+    fd = FoldDesc()
+    fd.W, fd.beta, fd.b, fd.out, fd.rows, fd.cols, fd.ldw, fd.blk0 = Wd.data_ptr(), btd.data_ptr(), bd.data_ptr(), bf.data_ptr(), n, d, d, 0
+    ops.fold_bias(ops.device_table([fd]), 1, (n + 3) // 4)
+    close(bf, (W @ beta + b).detach(), 1e-5, "folded bias")
+
+    # forward through the folded operands (fp32 check of the algebra)
+    close((xhat @ shadow[:, :d].float().cpu().T + bf.cpu()), y.detach(), 1e-4 if dtype == BPM_F32 else 5e-2, "folded forward")
+
+    # backward: dWf = dy^T xhat, dbf = colsum(dy)  ->  dW, db, dgamma, dbeta
+    dWf = (dy.T @ xhat).contiguous().to(DEV)
+    dbf = dy.sum(0).contiguous().to(DEV)
+    dW, db = torch.ones(n, d, device=DEV), torch.ones(n, device=DEV)
+    dg, dbt = torch.ones(d, device=DEV), torch.ones(d, device=DEV)
+    ud = UnfoldDesc()
+    ud.dWf, ud.dbf, ud.W, ud.gamma, ud.beta = dWf.data_ptr(), dbf.data_ptr(), Wd.data_ptr(), gd.data_ptr(), btd.data_ptr()
+    ud.dW, ud.dbias, ud.dgamma, ud.dbeta = dW.data_ptr(), db.data_ptr(), dg.data_ptr(), dbt.data_ptr()
+    ud.rows, ud.cols, ud.ldw, ud.blk0 = n, d, d, 0
+    ops.unfold_grads(ops.device_table([ud]), 1, (n + 15) // 16)
+    close(dW, 1 + W.grad, 2e-4, "unfolded dW")
+    close(db, 1 + b.grad, 2e-4, "unfolded dbias")
+    close(dg, 1 + gamma.grad, 2e-4, "unfolded dgamma")
+    close(dbt, 1 + beta.grad, 2e-4, "unfolded dbeta")
+
+
+def test_attention_backward_halves_and_side_stream():
+    """bpm_attn_bwd_dq + bpm_attn_bwd_dkv == bpm_attn_bwd; bpm_stream_create gives a usable stream."""
+    import ctypes as C
+    from bpmult_amd import _lib
+    dtype, B, H, T, S, dh, dhp = BPM_BF16, 2, 2, 96, 80, 25, 32
+    ct = ops.ct_torch(dtype)
+    mk = lambda L, seed: (torch.randn(B, H, L, dhp, generator=torch.Generator().manual_seed(seed)) * 0.5).to(ct).to(DEV)
+    Q, K, V, dO = mk(T, 1), mk(S, 2), mk(S, 3), mk(T, 4)
+    ld = pad32(H * dh)
+    O = torch.zeros(T * B, ld, device=DEV, dtype=ct)
+    lse = torch.zeros(B, H, T, device=DEV)
+    res = []
+    for split in (False, True):
+        delta = torch.zeros(B, H, T, device=DEV)
+        dQ, dK, dV = (torch.zeros(n * B, ld, device=DEV, dtype=ct) for n in (T, S, S))
+        p = ops.attn_problem(Q, K, V, O, ld, lse, B, H, T, S, dh, dhp, 1 + abs(S - T), dO=dO, delta=delta, dQ=dQ, lddq=ld,
+                             dK=dK, lddk=ld, dV=dV, lddv=ld, dq_scale=dh ** -0.5, drop_p=0.1, drop_site=3)
+        ops.attn_fwd(dtype, [p], 11)
+        if split:
+            out = C.c_void_p()
+            _lib.check(_lib.lib().bpm_stream_create(1, C.byref(out)), "bpm_stream_create")
+            side = torch.cuda.ExternalStream(out.value)
+            ops.attn_bwd_dq(dtype, [p], 11)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ops.attn_bwd_dkv(dtype, [p], 11)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            ops.attn_bwd(dtype, [p], 11)
+        torch.cuda.synchronize()
+        res.append([t.float().cpu() for t in (dQ, dK, dV, delta)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert res[0][0].abs().sum() > 0 and res[0][1].abs().sum() > 0
