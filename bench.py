@@ -187,7 +187,8 @@ def main():
     sync = GradSync(model)
     batch = synth_batch(c, B, 1234 + rank, dev)
     crit = torch.nn.BCEWithLogitsLoss()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from bpmult_amd.optim import FusedAdam
+    opt = FusedAdam(model, lr=1e-3)          # one kernel over the flat trunk buffers (reported as optimizer_ms, not timed)
 
     def step():
         for p in model.parameters():
@@ -229,7 +230,8 @@ def main():
     _lib.check(L.bpm_prof_collect(kinds[dom], C.byref(ms), C.byref(work), C.byref(n)), "bpm_prof_collect")
     L.bpm_prof_enable(0)
 
-    # optimizer step, reported separately (not part of the fwd+bwd metric)
+    # optimizer step, reported separately (not part of the fwd+bwd metric); one untimed step allocates the moments
+    opt.step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(3):

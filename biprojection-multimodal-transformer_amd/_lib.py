@@ -146,6 +146,7 @@ SIGNATURES = {
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
+    "bpm_adam_step": [_P, _P, _P, _P, C.c_size_t, _F, _F, _F, _F, _F, _I, _F, _I, _P],
     "bpm_stream_create": [_I, C.POINTER(C.c_void_p)],
     "bpm_stream_priority_range": [C.POINTER(_I), C.POINTER(_I)],
     "bpm_prof_enable": [C.c_uint],

@@ -38,7 +38,10 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int KT = 64;      // keys per tile (forward / dQ)
-constexpr int QT = 32;      // queries per tile (dK/dV)
+#ifndef BPM_ATTN_QT
+#define BPM_ATTN_QT 32
+#endif
+constexpr int QT = BPM_ATTN_QT;      // queries per tile (dK/dV): a multiple of 32
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct AProb {
@@ -444,9 +447,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
         __syncthreads();
         if (qt + 1 < qt_hi) stage(qt + 1);
         const bool edge = (qt * QT < ilo_max) || (qt * QT + QT > P.T);
-        f32x4 pd[2], ds[2];
+        constexpr int NU = QT / 16;
+        f32x4 pd[NU], ds[NU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < C::NKS; ++s) {

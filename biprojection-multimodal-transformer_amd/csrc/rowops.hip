@@ -9,6 +9,8 @@
 // independent problems (the encoders of one level run in lock-step), passed
 // by value in the kernel-argument segment; a block finds its problem from a
 // prefix table of block counts.
+#include <cmath>
+
 #include "bpm_common.h"
 #include "../../include/bpmult_hip.h"
 
@@ -688,6 +690,39 @@ static int fill_embed(Grp<EmbP>& g, const bpm_embed_problem* q, int n, int d, ui
         p.drop = make_drop(q[i].drop_p, seed, q[i].drop_site);
         g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)p.T * p.B * d, NT * 4, CAP);
     }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Fused Adam over one flat fp32 buffer (torch.optim.Adam semantics, no amsgrad):
+//   g = grad * grad_scale + wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),   bc_i = 1 - b_i^t  (passed in)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, size_t n4, float lr_c, float b1, float b2, float eps,
+                                                 float wd, float rsq_bc2, float gscale, int zero_grad) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        gg = gg * gscale + wd * pp;
+        mm = b1 * mm + (1.f - b1) * gg;
+        vv = b2 * vv + (1.f - b2) * gg * gg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pp[q] -= lr_c * mm[q] / (sqrtf(vv[q]) * rsq_bc2 + eps);
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        if (zero_grad) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+extern "C" int bpm_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n == 0 || (n & 3) || step < 1) return BPM_ERR_ARG;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return BPM_ERR_ALIGN;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const size_t n4 = n / 4;
+    const unsigned blocks = blocks_for(n4, NT, 256 * 16);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n4,
+                       (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad);
+    BPM_CHECK_LAUNCH();
     return 0;
 }
 

@@ -239,6 +239,14 @@ typedef struct bpm_gmu_problem {
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
+/* Fused Adam step over ONE flat fp32 buffer (replaces torch.optim.Adam's per-tensor loop of
+ * train.py:123-125,396-398 for the trunk, whose parameters / gradients are views into flat buffers).
+ * torch.optim.Adam semantics (no amsgrad, L2 weight decay folded into the gradient); `step` is the 1-based step
+ * count for the bias corrections; grad_scale multiplies the gradient first (1/world after an all-reduce sum);
+ * zero_grad != 0 clears the gradient in the same pass.  n % 4 == 0, 16-byte aligned pointers. */
+int bpm_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
 /* Engine plumbing (no reference counterpart): a non-blocking HIP stream at the device's lowest priority
  * (low_priority != 0) or at the default priority.  The host engine puts weight-gradient GEMMs and the
  * key/value-side chain there so that the dispatcher serves the critical-path stream first. */

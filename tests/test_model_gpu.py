@@ -124,3 +124,57 @@ def test_f9_cfg1_shape(prec):
     inputs = {"xl": T(det("f9.xl", (2, 20, 768))), "img": T(det("f9.img", (2, 500, 35))), "aud": T(det("f9.aud", (2, 400, 74)))}
     run_model(g, model, "f9.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec,
               BF16_GRAD=BF16_GRAD)
+
+
+def test_fused_adam_matches_torch_adam():
+    """bpmult_amd.optim.FusedAdam (one kernel over the flat trunk buffers) == torch.optim.Adam, three steps,
+    including the hand-off through refreshed weight shadows (the loss sequence must match too)."""
+    import copy
+    from bpmult_amd.optim import FusedAdam
+    torch.manual_seed(7)
+    a = args_for("mmtrvat", hidden_sz=24, num_heads=4, layers=2, orig_d_l=32)
+    m1 = get_model(a)
+    m2 = copy.deepcopy(m1)
+    m1.precision = m2.precision = "f32"
+    m1, m2 = m1.cuda().train(), m2.cuda().train()
+    x = [torch.randn(2, 50, 32, device="cuda"), torch.randn(2, 500, 35, device="cuda"), torch.randn(2, 375, 74, device="cuda")]
+    tgt = (torch.randn(2, 6, device="cuda") > 0).float()
+    o1 = torch.optim.Adam(m1.parameters(), lr=1e-2, weight_decay=0.0)
+    o2 = FusedAdam(m2, lr=1e-2)
+    for it in range(3):
+        losses = []
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(m(x[0], None, None, x[1], x[2]), tgt)
+            loss.backward()
+            o.step()
+            losses.append(float(loss.detach()))
+        assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0])), (it, losses)
+    # Adam normalises every element's step to ~lr, so elements whose gradient is rounding noise (atomics order
+    # differs between the two runs) may move differently: bound by a fraction of the 3 * lr they can travel
+    worst = 0.0
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        worst = max(worst, float((p1 - p2).abs().max()))
+    assert worst <= 3e-3, worst
+
+
+def test_fused_adam_kernel_exact():
+    """bpm_adam_step on given gradients == torch.optim.Adam on the same gradients (weight decay, grad_scale, fused zero)."""
+    from bpmult_amd import _lib
+    n = 4096 + 64
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-6, 1, (1,), generator=g))) for _ in range(4)]
+    ref = p0.clone().cuda().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for it, gr in enumerate(grads, 1):
+        ref.grad = (gr * 0.5).cuda()
+        opt.step()
+        gd = gr.clone().cuda()
+        _lib.check(_lib.lib().bpm_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 3e-3, 0.9, 0.98, 1e-8,
+                                            0.01, it, 0.5, 1, torch.cuda.current_stream().cuda_stream), "bpm_adam_step")
+        assert float(gd.abs().max()) == 0.0
+        d = float((p - ref.detach()).abs().max())
+        assert d <= 2e-6, (it, d)

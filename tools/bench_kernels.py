@@ -102,6 +102,8 @@ def main():
     gemm_case("NT qkv   (heads, bias)", GEMM_NT, R, d, d, ld, ld, 0, 3 * G, out_kind=OUT_HEADS, bias=True)
     gemm_case("NT out   (bias,resid,drop)", GEMM_NT, R, d, d, ld, ld, d, G, bias=True, resid=True, drop_p=0.1)
     gemm_case("NT out   (plain f32)", GEMM_NT, R, d, d, ld, ld, d, G)
+    gemm_case("NT out   (bias,resid) nodrop", GEMM_NT, R, d, d, ld, ld, d, G, bias=True, resid=True)
+    gemm_case("NT fc1   (relu,CT) nodrop", GEMM_NT, R, 4 * d, d, ld, ld, ld4, G, out_kind=OUT_CT, bias=True, flags=F_RELU)
     gemm_case("NT fc1   (relu,drop,CT)", GEMM_NT, R, 4 * d, d, ld, ld, ld4, G, out_kind=OUT_CT, bias=True, flags=F_RELU, drop_p=0.1)
     gemm_case("NT fc2   (bias,resid,drop)", GEMM_NT, R, d, 4 * d, ld4, ld4, d, G, bias=True, resid=True, drop_p=0.1)
     # ---- backward

@@ -12,17 +12,17 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r"(gemm_tiled_kernel|gemm_astat_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|ln_fwd_kernel|"
-                  r"ln_bwd_kernel|rows_cast_kernel|embed_pos_fwd_kernel|embed_pos_bwd_kernel|pack_rows_\w+_kernel|gmu2_\w+_kernel|"
+                  r"ln_bwd_kernel|ln_fwd_vec_kernel|ln_bwd_vec_kernel|rows_cast_kernel|colsum_kernel|fold_bias_kernel|"
+                  r"unfold_grads_kernel|embed_pos_fwd_kernel|embed_pos_bwd_kernel|pack_rows_\w+_kernel|gmu2_\w+_kernel|"
                   r"pack_weights_kernel)", name)
     if m:
         k = m.group(1)
         if k == "gemm_tiled_kernel":      # needs mangled names (rocprofv3 -M): the demangler garbles __bf16 templates
-            if "Lb0ELb0E" in name or "false, false" in name:
-                k += "<TN>"
-            elif "Lb1ELb1E" in name or "true, true" in name:
-                k += "<NT>"
-            elif "Lb1ELb0E" in name or "true, false" in name:
-                k += "<NN>"
+            m2 = re.search(r"gemm_tiled_kernelI(?:DF16b|f)Lb([01])ELb([01])E", name) or \
+                re.search(r"gemm_tiled_kernel<[^,]+, (true|false), (true|false)", name)
+            if m2:
+                xk, yk = (g in ("1", "true") for g in m2.groups())
+                k += "<NT>" if (xk and yk) else "<NN>" if xk else "<TN>"
             else:
                 k += "<?>"
         return k
