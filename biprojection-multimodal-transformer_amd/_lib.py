@@ -67,7 +67,8 @@ class AttnProblem(C.Structure):
                 ("dV", C.c_void_p), ("lddv", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("S", C.c_int),
                 ("dh", C.c_int), ("dhp", C.c_int), ("mask_off", C.c_int),
-                ("dq_scale", C.c_float), ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
+                ("dq_scale", C.c_float), ("drop_p", C.c_float), ("drop_site", C.c_uint32),
+                ("q_pos0", C.c_int), ("q_stride", C.c_int)]
 
 
 class PackProblem(C.Structure):
@@ -95,7 +96,7 @@ class UnfoldDesc(C.Structure):
 
 class EmbedProblem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("T", C.c_int), ("B", C.c_int), ("accumulate", C.c_int),
-                ("drop_p", C.c_float), ("drop_site", C.c_uint32)]
+                ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("pos0", C.c_int), ("pos_stride", C.c_int)]
 
 
 class LnProblem(C.Structure):

@@ -55,6 +55,7 @@ struct AProb {
     char* dV; int lddv;
     int B, H, T, S, dh;
     int mask_off;
+    int qpos0, qstride;   // query row i sits at time qpos0 + i*qstride (mask rule only)
     float dq_scale;
     DropCfg drop;
     int blk0, nblk;     // block prefix / blocks per (b,h)
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int q_hi = min(P.T, qb * 64 + 64) - 1;
-    const int jend = min(P.S, q_hi + P.mask_off);      // one past the last key any query of this block sees (mask_off < 2^30)
+    const int jend = min(P.S, P.qpos0 + q_hi * P.qstride + P.mask_off);      // one past the last key any query of this block sees (mask_off < 2^30)
     const int ntile = (jend + KT - 1) / KT;
-    const int lim = min(P.S, q + P.mask_off);          // this lane sees keys j < lim
-    const int lim_min = min(P.S, q0 + P.mask_off);     // every lane of the wave sees keys j < lim_min
+    const int lim = min(P.S, P.qpos0 + q * P.qstride + P.mask_off);          // this lane sees keys j < lim
+    const int lim_min = min(P.S, P.qpos0 + q0 * P.qstride + P.mask_off);     // every lane of the wave sees keys j < lim_min
     const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
     const bool pair_ok = (P.S & 1) == 0;               // row starts are even: keys (2m, 2m+1) are hash pairs
@@ -312,10 +313,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
     for (int n = 0; n < C::ND; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int q_hi = min(P.T, qb * 64 + 64) - 1;
-    const int jend = min(P.S, q_hi + P.mask_off);
+    const int jend = min(P.S, P.qpos0 + q_hi * P.qstride + P.mask_off);
     const int ntile = (jend + KT - 1) / KT;
-    const int lim = min(P.S, q + P.mask_off);
-    const int lim_min = min(P.S, q0 + P.mask_off);
+    const int lim = min(P.S, P.qpos0 + q * P.qstride + P.mask_off);
+    const int lim_min = min(P.S, P.qpos0 + q0 * P.qstride + P.mask_off);
     const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
     const bool pair_ok = (P.S & 1) == 0;               // row starts are even: keys (2m, 2m+1) are hash pairs
@@ -417,9 +418,11 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp
     for (int n = 0; n < C::ND; ++n) { dk[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // query i sees key j iff i >= ilo = j - mask_off + 1 (and i < T, j < S)
-    const int ilo = (j < P.S) ? j - P.mask_off + 1 : (1 << 30);
-    const int ilo_max = (j0 + 15 < P.S) ? j0 + 15 - P.mask_off + 1 : (1 << 30);   // wave-uniform: tiles at or above it need no test
-    const int i_first = max(0, kb * 64 - P.mask_off + 1);                            // first query that sees any key of the block
+    // in ROW indices: row i sits at time qpos0 + i*qstride, so "time >= tmin" is "i >= ceil((tmin - qpos0) / qstride)"
+    auto first_row = [&](int tmin) { const int a = tmin - P.qpos0; return a <= 0 ? 0 : (a + P.qstride - 1) / P.qstride; };
+    const int ilo = (j < P.S) ? first_row(j - P.mask_off + 1) : (1 << 30);
+    const int ilo_max = (j0 + 15 < P.S) ? first_row(j0 + 15 - P.mask_off + 1) : (1 << 30);   // wave-uniform: tiles at or above it need no test
+    const int i_first = first_row(kb * 64 - P.mask_off + 1);                                   // first query row that sees any key of the block
     const int qt_lo = i_first / QT;
     const int qt_hi = (P.T + QT - 1) / QT;
     const bool dropping = P.drop.thresh != 0;
@@ -514,6 +517,9 @@ int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S,
         p.dQ = (char*)q.dQ; p.lddq = q.lddq; p.dK = (char*)q.dK; p.lddk = q.lddk; p.dV = (char*)q.dV; p.lddv = q.lddv;
         p.B = q.B; p.H = q.H; p.T = q.T; p.S = q.S; p.dh = q.dh;
         p.mask_off = (q.mask_off > 0 && q.mask_off < (1 << 29)) ? q.mask_off : (1 << 29);
+        if (q.q_pos0 < 0 || q.q_stride < 0 || q.q_pos0 > (1 << 24) || q.q_stride > (1 << 24)) return BPM_ERR_ARG;
+        p.qpos0 = q.q_pos0; p.qstride = q.q_stride > 0 ? q.q_stride : 1;
+        if ((long)p.qpos0 + (long)(q.T - 1) * p.qstride > (1l << 28)) return BPM_ERR_ARG;
         p.dq_scale = q.dq_scale;
         p.drop = bpm_make_drop(q.drop_p, seed, q.drop_site);
         p.nblk = ((blocks_over_S ? q.S : q.T) + 63) / 64;
@@ -533,7 +539,10 @@ double useful_pair_flops(const bpm_attn_problem* probs, int nprob) {
         double pairs = 0;
         if (q.mask_off <= 0) pairs = (double)q.T * q.S;
         else
-            for (int t = 0; t < q.T; ++t) pairs += (double)((long)t + q.mask_off < (long)q.S ? t + q.mask_off : q.S);
+            for (int t = 0; t < q.T; ++t) {
+                const long tt = (long)q.q_pos0 + (long)t * (q.q_stride > 0 ? q.q_stride : 1);
+                pairs += (double)(tt + q.mask_off < (long)q.S ? tt + q.mask_off : q.S);
+            }
         tot += pairs * q.dh * q.B * q.H;
     }
     return tot;

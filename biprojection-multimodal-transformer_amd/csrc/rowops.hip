@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc*
 //   out = dropout(scale * x + table[pos]),  pos = t+1 if x[t,b,0] != 0 else 0
 // backward: dx (+)= scale * drop_mult * dy   (the positional term is detached)
 // ---------------------------------------------------------------------------
-struct EmbP { const float* x; float* out; int T, B; int accumulate; DropCfg drop; };
+struct EmbP { const float* x; float* out; int T, B; int accumulate; int pos0, pstride; DropCfg drop; };
 
 __global__ void embed_pos_fwd_kernel(const Grp<EmbP> grp, const float* __restrict__ table, int d, float scale) {
     unsigned bid = blockIdx.x, nblk;
@@ -193,7 +193,7 @@ __global__ void embed_pos_fwd_kernel(const Grp<EmbP> grp, const float* __restric
         const int c = (int)(i % d);
         const size_t row = i / d;
         const int t = (int)(row / P.B);
-        const int pos = (P.x[row * d] != 0.f) ? t + 1 : 0;
+        const int pos = (P.x[row * d] != 0.f) ? P.pos0 + t * P.pstride + 1 : 0;     // row t sits at time pos0 + t*pstride
         P.out[i] = (scale * P.x[i] + table[(size_t)pos * d + c]) * bpm_drop_mult(P.drop, (uint32_t)i);
     }
 }
@@ -687,6 +687,8 @@ static int fill_embed(Grp<EmbP>& g, const bpm_embed_problem* q, int n, int d, ui
         if (!q[i].x || !q[i].out || q[i].T < 1 || q[i].B < 1) return BPM_ERR_ARG;
         EmbP& p = g.p[i];
         p.x = q[i].x; p.out = q[i].out; p.T = q[i].T; p.B = q[i].B; p.accumulate = q[i].accumulate;
+        if (q[i].pos0 < 0 || q[i].pos_stride < 0) return BPM_ERR_ARG;
+        p.pos0 = q[i].pos0; p.pstride = q[i].pos_stride > 0 ? q[i].pos_stride : 1;
         p.drop = make_drop(q[i].drop_p, seed, q[i].drop_site);
         g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)p.T * p.B * d, NT * 4, CAP);
     }
@@ -747,7 +749,7 @@ extern "C" int bpm_embed_pos_fwd(const bpm_embed_problem* q, int n, const float*
     if (rc) return rc;
     if (!table) return BPM_ERR_ARG;
     for (int i = 0; i < n; ++i)
-        if (table_rows < q[i].T + 1) return BPM_ERR_ARG;
+        if (table_rows < q[i].pos0 + (q[i].T - 1) * (q[i].pos_stride > 0 ? q[i].pos_stride : 1) + 2) return BPM_ERR_ARG;
     hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, table, d, scale);
     BPM_CHECK_LAUNCH();
     return 0;

@@ -236,6 +236,11 @@ class EncoderDesc:
     T: int
     S: int
     attn_dropout: float
+    # the T query rows are rows q_pos0 + i*q_stride of a length-T_full sequence (a gathered subset: SURVEY A.10);
+    # positions and the attention mask follow the ORIGINAL time steps
+    q_pos0: int = 0
+    q_stride: int = 1
+    T_full: Optional[int] = None
 
 
 @dataclass
@@ -339,7 +344,9 @@ class EncoderGroupPlan:
             b["dke"], b["dve"] = z(Rk, d), z(Rk, d)
             b["dxq"], b["dxk"], b["dxv"] = z(e.T, B, d), z(e.S, B, d), z(e.S, B, d)
             self.buf.append(b)
-        self.table = sinusoid_table(max(max(e.T, e.S) for e in self.encs) + 1, d, dev)
+        if cfg.biprojection and any(e.T_full is not None for e in self.encs):
+            raise ValueError("a gathered query subset is only exact for crossmodal (non-biprojection) encoders")
+        self.table = sinusoid_table(max(max(e.T_full or e.T, e.S) for e in self.encs) + 2, d, dev)
         self._ones, self._zeros = torch.ones(d, device=dev), torch.zeros(d, device=dev)
         # table of the launch that turns folded K/V gradients into in_proj / LayerNorm parameter gradients
         lnK = 1 if cfg.biprojection else 0
@@ -434,7 +441,8 @@ class EncoderGroupPlan:
                 kvp.append(proj_kv(b["khat"], 1, b["kh"][i]))
                 kvp.append(proj_kv(b["vhat"], 2, b["vh"][i]))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
-                                            self._mask_off(e.T, e.S), drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
+                                            self._mask_off(e.T_full or e.T, e.S), drop_p=pr(e.attn_dropout),
+                                            drop_site=site(e.enc_id, i, S_ATTN), q_pos0=e.q_pos0, q_stride=e.q_stride))
                 outp.append(ops.gemm_problem(b["ao"][i], st.sptr(wo), b["xmid"][i], R, d, d, ld, ld, d,
                                              bias_n=P("self_attn.out_proj.bias"), resid=resid_src, ldr=d,
                                              drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES1)))
@@ -537,7 +545,8 @@ class EncoderGroupPlan:
             for t, n in ((q, e.T), (k, e.S), (v, e.S)):
                 if tuple(t.shape) != (n, B, d) or not t.is_contiguous() or t.dtype != torch.float32:
                     raise ValueError(f"encoder {e.prefix}: expected contiguous fp32 [{n},{B},{d}], got {tuple(t.shape)} {t.dtype}")
-            emb += [ops.embed_problem(q, b["x"][0], e.T, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_Q)),
+            emb += [ops.embed_problem(q, b["x"][0], e.T, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_Q), pos0=e.q_pos0,
+                                      pos_stride=e.q_stride),
                     ops.embed_problem(k, b["ke"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_K)),
                     ops.embed_problem(v, b["ve"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_V))]
         ops.embed_pos_fwd(emb, self.table, d, math.sqrt(d), seed)
@@ -595,9 +604,10 @@ class EncoderGroupPlan:
                 dg_out.append(ops.gemm_problem(dy, st.sptr(wo), dao, R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                heads=(B, H, e.T, dh, dhp)))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
-                                            self._mask_off(e.T, e.S), dO=dao, delta=delta, dQ=dq, lddq=ld,
+                                            self._mask_off(e.T_full or e.T, e.S), dO=dao, delta=delta, dQ=dq, lddq=ld,
                                             dK=dk, lddk=ld, dV=dv, lddv=ld, dq_scale=self.scale,
-                                            drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN)))
+                                            drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN),
+                                            q_pos0=e.q_pos0, q_stride=e.q_stride))
                 ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
                 # query projection: gradients go straight to the parameters.  Key / value projections ran with the
                 # LayerNorm folded in: their bias column sums and weight gradients (against khat / vhat) land in

@@ -19,6 +19,7 @@ zero-padding is device agnostic; `--hybrid` is not supported (broken upstream).
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -138,12 +139,26 @@ class _Trunk:
                         model.attn_mask, model.four_modal)
         adrop = {"l": model.attn_dropout, "a": model.attn_dropout_a, "v": model.attn_dropout_v}
         e1 = [EncoderDesc(n + ".", ENC_ORDER.index(n), self.N[q], self.N[kv], adrop[key]) for n, (q, kv, key) in LEVEL1.items()]
-        e2 = [EncoderDesc(n + ".", ENC_ORDER.index(n), self.N[q], self.N[LEVEL1[src][0]], adrop[key])
-              for n, (q, src, key) in LEVEL2.items()]
+        # Exact dead-row elimination (verified on the reference): in a crossmodal encoder a query row
+        # never sees another query row (keys / values come from the other source in every layer), the Fusion-GMU is
+        # position-wise, and the head consumes only rows 0 and N-1 (mmtr.py:808,830,852).  So the level-2 encoders
+        # and the GMUs only need those two query rows; level 1 stays dense (it is level 2's key / value source).
+        self.prune = bool(getattr(model, "prune_unused_rows", False)) and not model.four_modal and min(self.N.values()) >= 2
+        self.Ng = {k: (2 if self.prune else n) for k, n in self.N.items()}            # rows of level-2 / GMU tensors
+        if self.prune:
+            self.idx = {k: torch.tensor([0, n - 1], device=dev) for k, n in self.N.items()}
+            self.pxg = {k: z(2, B, d) for k in self.N}
+            e2 = [EncoderDesc(n + ".", ENC_ORDER.index(n), 2, self.N[LEVEL1[src][0]], adrop[key], q_pos0=0,
+                              q_stride=self.N[q] - 1, T_full=self.N[q]) for n, (q, src, key) in LEVEL2.items()]
+        else:
+            e2 = [EncoderDesc(n + ".", ENC_ORDER.index(n), self.N[q], self.N[LEVEL1[src][0]], adrop[key])
+                  for n, (q, src, key) in LEVEL2.items()]
         self.plan1 = EncoderGroupPlan(st, cfg1, e1, B)
         self.plan2 = EncoderGroupPlan(st, cfg2, e2, B)
         self.out1 = {n: b["out"] for n, b in zip(LEVEL1, self.plan1.buf)}
         self.out2 = {n: b["out"] for n, b in zip(LEVEL2, self.plan2.buf)}
+        if self.prune:                      # rows 0 and N-1 of every level-1 output, as the GMUs see them
+            self.out1g = {n: z(2, B, d) for n in LEVEL1}
         # ---- time-axis maps (4-modal only)
         self.tmap: Dict[Tuple[str, str], dict] = {}
         if model.four_modal:
@@ -159,10 +174,10 @@ class _Trunk:
         # ---- dense Fusion-GMU layers: per target modality a "middle" and a "top" unit
         self.g: Dict[Tuple[str, str], dict] = {}
         for tgt in ("l", "a", "v"):
-            R = self.N[tgt] * B
+            R = self.Ng[tgt] * B
             for kind in ("mid", "top"):
                 self.g[(tgt, kind)] = dict(R=R, x1=z(R, d), x2=z(R, d), xc=z(R, 2 * self.ld, dt=ct), a1=z(R, d), a2=z(R, d),
-                                           ag=z(R, d), out=z(self.N[tgt], B, d), da1=z(R, self.ld, dt=ct),
+                                           ag=z(R, d), out=z(self.Ng[tgt], B, d), da1=z(R, self.ld, dt=ct),
                                            da2=z(R, self.ld, dt=ct), dag=z(R, self.ld, dt=ct), dx1=z(R, d), dx2=z(R, d))
         self._build_gmu()
         self._conv_cache = {}
@@ -269,7 +284,9 @@ class _Trunk:
     def _lvl1(self, tgt: str, name: str) -> torch.Tensor:
         """Level-1 output as the fusion of target `tgt` sees it (through the time map in the 4-modal model)."""
         t = self.tmap.get((tgt, name))
-        return t["out"] if t is not None else self.out1[name]
+        if t is not None:
+            return t["out"]
+        return self.out1g[name] if self.prune else self.out1[name]
 
     def _build_gmu(self) -> None:
         B, d, ld, st = self.B, self.d, self.ld, self.st
@@ -294,7 +311,7 @@ class _Trunk:
                 gemms.append(ops.gemm_problem(xc2, st.sptr(w2), g["a2"], R, d, d, 2 * ld, ld, d))
                 gemms.append(ops.gemm_problem(xc1, st.sptr(wg_), g["ag"], R, d, 2 * ld, 2 * ld, 2 * ld, d))
                 gates.append(ops.gmu_problem(g["a1"], g["a2"], g["ag"], g["x1"], g["x2"], R, out=g["out"]))
-                g["dout"] = torch.zeros(self.N[tgt], B, d, device=st.device)
+                g["dout"] = torch.zeros(self.Ng[tgt], B, d, device=st.device)
                 bw_gate.append(ops.gmu_problem(g["a1"], g["a2"], g["ag"], g["x1"], g["x2"], R, dout=g["dout"], da1=g["da1"], da2=g["da2"],
                                                dag=g["dag"], ldg=ld, dx1=g["dx1"], dx2=g["dx2"]))
                 bw_wg += [ops.gemm_problem(g["da1"], xc1, st.gptr(w1), d, d, R, ld, 2 * ld, d, flags=F_ACCUM),
@@ -331,7 +348,14 @@ class _Trunk:
         q1 = [px[q] for (q, kv, _) in LEVEL1.values()]
         k1 = [px[kv] for (q, kv, _) in LEVEL1.values()]
         self.plan1.forward(q1, k1, k1, seed, training)
-        q2 = [px[q] for (q, src, _) in LEVEL2.values()]
+        if self.prune:
+            for k in self.N:
+                torch.index_select(px[k], 0, self.idx[k], out=self.pxg[k])
+            for n, (q, _, _) in LEVEL1.items():
+                torch.index_select(self.out1[n], 0, self.idx[q], out=self.out1g[n])
+            q2 = [self.pxg[q] for (q, src, _) in LEVEL2.values()]
+        else:
+            q2 = [px[q] for (q, src, _) in LEVEL2.values()]
         k2 = [self.out1[src] for (q, src, _) in LEVEL2.values()]
         self.plan2.forward(q2, k2, k2, seed, training)
         self._time_forward()
@@ -358,7 +382,7 @@ class _Trunk:
         for tgt in ("l", "a", "v"):
             l2a, l1a, l2b, l1b = FUSE[tgt]
             top, mid = self.g[(tgt, "top")], self.g[(tgt, "mid")]
-            shp = (self.N[tgt], self.B, self.d)
+            shp = (self.Ng[tgt], self.B, self.d)
             d2[l2a], d2[l2b] = top["dx1"].view(shp), top["dx2"].view(shp)
             for name, gsum in ((l1a, top["dx1"] + mid["dx1"]), (l1b, top["dx2"] + mid["dx2"])):
                 if (tgt, name) in self.tmap:
@@ -372,17 +396,25 @@ class _Trunk:
         dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2])
         self._ready("level2")
         for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
-            d1[src] = d1[src] + gk + gv
+            if self.prune:                   # the GMU terms only touch rows 0 and N-1 of the level-1 output
+                full = gk + gv
+                full.index_add_(0, self.idx[LEVEL1[src][0]], d1[src])
+                d1[src] = full
+            else:
+                d1[src] = d1[src] + gk + gv
         dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1])
         self._ready("level1")
         acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
             acc[q].append(gq)
             acc[kv] += [gk, gv]
+        small: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, src, _)), gq in zip(LEVEL2.items(), dq2):
-            acc[q].append(gq)
+            (small if self.prune else acc)[q].append(gq)
         for k, terms in acc.items():
             torch.sum(torch.stack(terms), dim=0, out=self.dpx[k])
+            for gq in small[k]:
+                self.dpx[k].index_add_(0, self.idx[k], gq)
         res = self.conv_backward(seed, need_dx)
         self._ready("proj")
         st.end_backward()
@@ -430,6 +462,9 @@ class _BPMulTBase(nn.Module):
         self.relu_dropout, self.res_dropout = args.relu_dropout, args.res_dropout
         self.out_dropout, self.embed_dropout, self.attn_mask = args.out_dropout, args.embed_dropout, args.attn_mask
         self.precision: Optional[str] = getattr(args, "precision", None)
+        # exact dead-row elimination in level 2 + GMUs (3-modal model only; see _Trunk); off by default so that the
+        # default schedule is the reference's dense one
+        self.prune_unused_rows = bool(getattr(args, "prune_unused_rows", False)) or os.environ.get("BPMULT_PRUNE") == "1"
         d = self.d
         self.enc = BertEncoder(args)
         for t in ("l", "v", "a"):
@@ -518,6 +553,12 @@ class _BPMulTBase(nn.Module):
         if B not in self._trunks:
             self._trunks[B] = _Trunk(self, B)
         return self._trunks[B]
+
+    def set_prune_unused_rows(self, flag: bool) -> None:
+        """Switch the level-2 / GMU schedule between dense (reference) and rows {0, N-1} only (same logits and
+        gradients).  Launch tables are rebuilt on the next forward."""
+        self.prune_unused_rows = bool(flag)
+        self._trunks = {}
 
     def _next_seed(self) -> int:
         self._step += 1

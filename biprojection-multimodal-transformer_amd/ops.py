@@ -95,8 +95,9 @@ def gemm_grouped(dtype: int, variant: int, probs, seed: int = 0, n: Optional[int
 # attention
 # ----------------------------------------------------------------------------
 def attn_problem(Q, K, V, O, ldo, lse, B, H, T, S, dh, dhp, mask_off, *, dO=None, delta=None, dQ=None, lddq=0,
-                 dK=None, lddk=0, dV=None, lddv=0, dq_scale=1.0, drop_p=0.0, drop_site=0) -> AttnProblem:
+                 dK=None, lddk=0, dV=None, lddv=0, dq_scale=1.0, drop_p=0.0, drop_site=0, q_pos0=0, q_stride=1) -> AttnProblem:
     p = AttnProblem()
+    p.q_pos0, p.q_stride = q_pos0, q_stride
     p.Q, p.K, p.V, p.O, p.ldo, p.lse = _p(Q), _p(K), _p(V), _p(O), ldo, _f32(lse, "lse")
     p.dO, p.delta = _p(dO), _f32(delta, "delta")
     p.dQ, p.lddq, p.dK, p.lddk, p.dV, p.lddv = _p(dQ), lddq, _p(dK), lddk, _p(dV), lddv
@@ -173,10 +174,11 @@ def unfold_grads(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None
     _lib.check(_lib.lib().bpm_unfold_grads(table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_unfold_grads")
 
 
-def embed_problem(x, out, T, B, *, accumulate=False, drop_p=0.0, drop_site=0) -> EmbedProblem:
+def embed_problem(x, out, T, B, *, accumulate=False, drop_p=0.0, drop_site=0, pos0=0, pos_stride=1) -> EmbedProblem:
     p = EmbedProblem()
     p.x, p.out, p.T, p.B = _f32(x, "embed.x"), _f32(out, "embed.out"), T, B
     p.accumulate, p.drop_p, p.drop_site = int(accumulate), drop_p, drop_site
+    p.pos0, p.pos_stride = pos0, pos_stride
     return p
 
 

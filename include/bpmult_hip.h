@@ -110,6 +110,8 @@ typedef struct bpm_attn_problem {
     float dq_scale;
     float drop_p;           /* on P, element index ((b*H+h)*T + i)*S + j, keyed by (call seed, drop_site) */
     uint32_t drop_site;
+    int q_pos0, q_stride;   /* query row i is time step q_pos0 + i*q_stride for the mask rule (stride 0 = 1): a
+                               gathered subset of query rows keeps its original visibility */
 } bpm_attn_problem;
 
 int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
@@ -185,6 +187,8 @@ typedef struct bpm_embed_problem {
     int T, B;
     int accumulate;                         /* backward only */
     float drop_p; uint32_t drop_site;       /* element index (t*B + b)*d + c */
+    int pos0, pos_stride;                   /* row t is time step pos0 + t*pos_stride (stride 0 = 1): a gathered
+                                               subset of rows keeps its original positions */
 } bpm_embed_problem;
 int bpm_embed_pos_fwd(const bpm_embed_problem* probs, int n, const float* table, int table_rows, int d,
                       float scale, uint64_t seed, void* stream);

@@ -455,3 +455,48 @@ def test_attention_backward_halves_and_side_stream():
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert res[0][0].abs().sum() > 0 and res[0][1].abs().sum() > 0
+
+
+def test_gathered_query_rows_keep_positions():
+    """q_pos0 / q_stride (attention) and pos0 / pos_stride (embedding): rows {0, T-1} computed alone == the same
+    rows of the full computation."""
+    from oracle import bpmult_cpu as O
+    dtype, B, H, T, S, dh, dhp = BPM_F32, 2, 2, 40, 40, 8, 32
+    ct = ops.ct_torch(dtype)
+    gen = torch.Generator().manual_seed(5)
+    mk = lambda L: torch.cat([torch.randn(B, H, L, dh, generator=gen) * 0.5, torch.zeros(B, H, L, dhp - dh)], -1)
+    Q, K, V, dO = mk(T), mk(S), mk(S), mk(T)
+    ld = pad32(H * dh)
+    idx = torch.tensor([0, T - 1])
+
+    def run(Qx, dOx, Tn, **pos):
+        O_ = torch.zeros(Tn * B, ld, device=DEV, dtype=ct)
+        lse, delta = torch.zeros(B, H, Tn, device=DEV), torch.zeros(B, H, Tn, device=DEV)
+        dQ, dK, dV = (torch.zeros(n * B, ld, device=DEV, dtype=ct) for n in (Tn, S, S))
+        keep = [t.contiguous().to(ct).to(DEV) for t in (Qx, K, V, dOx)]
+        p = ops.attn_problem(keep[0], keep[1], keep[2], O_, ld, lse, B, H, Tn, S, dh, dhp, 1 + abs(S - T), dO=keep[3], delta=delta,
+                             dQ=dQ, lddq=ld, dK=dK, lddk=ld, dV=dV, lddv=ld, dq_scale=1.0, **pos)
+        ops.attn_fwd(dtype, [p], 0)
+        ops.attn_bwd(dtype, [p], 0)
+        torch.cuda.synchronize()
+        return O_.view(Tn, B, ld).cpu(), dQ.view(Tn, B, ld).cpu(), dK.cpu(), dV.cpu()
+
+    # dense run with only rows {0, T-1} of dO non-zero, vs the 2-row run with original positions
+    dO_sparse = torch.zeros_like(dO)
+    dO_sparse[:, :, idx] = dO[:, :, idx]
+    Of, dQf, dKf, dVf = run(Q, dO_sparse, T)
+    Og, dQg, dKg, dVg = run(Q[:, :, idx], dO[:, :, idx], 2, q_pos0=0, q_stride=T - 1)
+    close(Og, Of[idx], 1e-5, "gathered O")
+    close(dQg, dQf[idx], 1e-5, "gathered dQ")
+    close(dKg, dKf, 1e-5, "gathered dK")
+    close(dVg, dVf, 1e-5, "gathered dV")
+    assert float(Og[0].abs().sum()) > 0 and not torch.allclose(Og[0], Og[1])      # row 0 sees one key, row T-1 all
+
+    d, T2 = 24, 9
+    x = rnd(T2, 3, d, seed=91)
+    table = O.sinusoid_table(T2 + 1, d).to(DEV)
+    full, part = torch.empty(T2, 3, d, device=DEV), torch.empty(2, 3, d, device=DEV)
+    xg = x[[0, T2 - 1]].contiguous().to(DEV)
+    ops.embed_pos_fwd([ops.embed_problem(x.to(DEV), full, T2, 3)], table, d, math.sqrt(d), seed=0)
+    ops.embed_pos_fwd([ops.embed_problem(xg, part, 2, 3, pos0=0, pos_stride=T2 - 1)], table, d, math.sqrt(d), seed=0)
+    close(part, full[[0, T2 - 1]].cpu(), 1e-6, "gathered embed_pos")
