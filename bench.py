@@ -18,6 +18,9 @@ the largest share of the warm-up is bracketed by HIP events on its launch stream
 during the timed steps (bpm_prof_*), achieved = algorithmic FLOPs / summed
 launch time.  `cpu_baseline` times the CPU oracle (oracle/bpmult_cpu.py, a port
 of the reference arithmetic) on a bounded sample of the same workload.
+`value` is always the reference's DENSE schedule; `pruned_schedule` is a second,
+separately timed figure for the exact dead-row elimination of SURVEY.md A.10
+(same logits and gradients, fewer executed flops) and is never the headline.
 """
 import argparse
 import ctypes as C
@@ -147,6 +150,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pruned", action="store_true", help="skip the secondary measurement of the pruned schedule")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1)
     a = ap.parse_args()
@@ -230,6 +234,31 @@ def main():
     _lib.check(L.bpm_prof_collect(kinds[dom], C.byref(ms), C.byref(work), C.byref(n)), "bpm_prof_collect")
     L.bpm_prof_enable(0)
 
+    # Secondary figure, never `value`: the same step with the exact dead-row elimination of SURVEY A.10 (level-2
+    # encoders and Fusion-GMUs on query rows {0, N-1} only; logits and gradients identical, tests/test_model_gpu.py).
+    pruned = None
+    if not a.no_pruned and c["model"] == "mmtrvat":
+        model.set_prune_unused_rows(True)
+        for _ in range(max(a.warmup, 1)):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dtp = time.perf_counter() - tp
+        if world > 1:
+            t = torch.tensor([dtp], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtp = float(t.item())
+        pruned = {"value": round(world * B * a.steps / dtp, 3), "unit": "samples/s", "ms_per_step": round(dtp / a.steps * 1e3, 3),
+                  "what": "same step, level-2 encoders + Fusion-GMUs on query rows {0, N-1} only (exact; SURVEY A.10)"}
+        model.set_prune_unused_rows(False)
+
     # optimizer step, reported separately (not part of the fwd+bwd metric); one untimed step allocates the moments
     opt.step()
     torch.cuda.synchronize()
@@ -256,6 +285,8 @@ def main():
                          "traffic": traffic, "launches": n.value, "avg_launch_ms": round(ms.value / max(n.value, 1), 4),
                          "flops_per_launch": work.value / max(n.value, 1)},
         }
+        if pruned is not None:
+            out["pruned_schedule"] = pruned
         print("[bench] gpu part done: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline")}), file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, a.cpu_batch, a.cpu_steps)
