@@ -32,13 +32,18 @@ class GradSync:
         self.active = True           # set False on non-final gradient-accumulation micro-steps
         model._grad_ready_hook = self._on_ready
 
-    def _on_ready(self, flat: torch.Tensor, lo: int, hi: int) -> None:
-        """Called by the trunk's backward when gflat[lo:hi] is final for this step."""
+    def _on_ready(self, flat: torch.Tensor, lo: int, hi: int, events=None) -> None:
+        """Called by the trunk's backward when gflat[lo:hi] is final for this step: once `events` have passed
+        (a layer's slice: its main- and side-stream work), or everything launched on the current stream so far."""
         if self.world == 1 or not self.active:
             return
         if self.comm is None:
             self.comm = torch.cuda.Stream(device=flat.device)
-        self.comm.wait_stream(torch.cuda.current_stream())
+        if events:
+            for ev in events:
+                self.comm.wait_event(ev)
+        else:
+            self.comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm):
             for a in range(lo, hi, self.bucket):
                 b = min(hi, a + self.bucket)

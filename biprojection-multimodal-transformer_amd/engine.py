@@ -350,9 +350,10 @@ class EncoderGroupPlan:
         self._ones, self._zeros = torch.ones(d, device=dev), torch.zeros(d, device=dev)
         # table of the launch that turns folded K/V gradients into in_proj / LayerNorm parameter gradients
         lnK = 1 if cfg.biprojection else 0
-        ud, blk = [], 0
-        for e, b in zip(self.encs, self.buf):
-            for i in range(L):
+        self._unfold = []                                  # one table per layer: its gradients are final with it
+        for i in range(L):
+            ud, blk = [], 0
+            for e, b in zip(self.encs, self.buf):
                 pn = lambda leaf: self._pn(e, i, leaf)
                 u = UnfoldDesc()
                 u.dWf, u.dbf = b["dWf"][i].data_ptr(), b["dbf"][i].data_ptr()
@@ -363,7 +364,7 @@ class EncoderGroupPlan:
                 u.rows, u.cols, u.ldw, u.blk0 = 2 * d, d, d, blk
                 blk += (2 * d + 15) // 16
                 ud.append(u)
-        self._unfold = (ops.device_table(ud), len(ud), blk)
+            self._unfold.append((ops.device_table(ud), len(ud), blk))
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
         self._bwd = {True: self._build_bwd(True), False: self._build_bwd(False)}
 
@@ -492,13 +493,17 @@ class EncoderGroupPlan:
         else:
             raise RuntimeError("unknown step")
 
-    def _run(self, steps, seed: int) -> None:
+    def _run(self, steps, seed: int, on_mark=None) -> None:
         """Launch a step table.  Plain steps go to the current ("main") stream.  (SIDE, step) goes to the side
         stream, ordered behind everything the main stream has launched so far; (MARK, k) records an event on the
         side stream; (WAIT, k) makes the main stream wait for mark k (no-op if it was never recorded); JOIN
         makes the main stream wait for all side work.  With BPMULT_SIDE=0 everything runs on the main stream."""
         if not _SIDE:
             for s in steps:
+                if s is not JOIN and s[0] is MARK and on_mark is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    on_mark(s[1], [ev])
                 if s is JOIN or s[0] is MARK or s[0] is WAIT:
                     continue
                 self._exec(s[1] if s[0] is SIDE else s, seed)
@@ -527,6 +532,10 @@ class EncoderGroupPlan:
                 if side_dirty:
                     marks[s[1]] = torch.cuda.Event()
                     marks[s[1]].record(side)
+                if on_mark is not None:             # everything launched for this mark so far, on both streams
+                    evm = torch.cuda.Event()
+                    evm.record(main)
+                    on_mark(s[1], [evm] + ([marks[s[1]]] if s[1] in marks else []))
             elif s[0] is WAIT:
                 if s[1] in marks:
                     main.wait_event(marks.pop(s[1]))
@@ -682,19 +691,18 @@ class EncoderGroupPlan:
                           self._gemm(GEMM_NN, s_dg0b),
                           self._gemm(GEMM_NN, s_dg0c),
                           (ops.ln_bwd, A(LnProblem, s_ln0), d)]
-            steps.append((MARK, i))
-        # d(khat), d(vhat) summed over the layers -> d(embedded key / value source): LayerNorm backward without
-        # affine; then the folded K/V parameter gradients of every layer in one launch
+            # folded K/V gradients of this layer -> in_proj / LayerNorm parameter gradients; with it every gradient of
+            # layer i is final once the side stream reaches MARK i and the main stream this point (all-reduce hook)
+            steps += [(SIDE, (ops.unfold_grads,) + self._unfold[i]), (MARK, i)]
+        # d(khat), d(vhat) summed over the layers -> d(embedded key / value source): LayerNorm backward without affine
         hat = []
         for e, b in zip(self.encs, self.buf):
             hat += [ops.ln_problem(b["ke"], self._ones, None, b["stk"][0], b["stk"][1], b["Rk"], dy=b["Gk"], ldy=d, dx=b["dke"]),
                     ops.ln_problem(b["ve"], self._ones, None, b["stv"][0], b["stv"][1], b["Rk"], dy=b["Gv"], ldy=d, dx=b["dve"])]
-        steps += [(SIDE, (ops.ln_bwd, A(LnProblem, hat), d)),
-                  (SIDE, (ops.unfold_grads,) + self._unfold),
-                  JOIN]
+        steps += [(SIDE, (ops.ln_bwd, A(LnProblem, hat), d)), JOIN]
         return steps
 
-    def backward(self, douts: Sequence[Optional[torch.Tensor]]):
+    def backward(self, douts: Sequence[Optional[torch.Tensor]], on_layer=None):
         """douts[e]: fp32 [T_e,B,d] gradient of encoder e's output (None = zero).  Returns the plan-owned
         gradients w.r.t. each encoder's query, key and value sources (three lists), and accumulates
         parameter gradients into the ParamStore's flat gradient buffer."""
@@ -719,7 +727,9 @@ class EncoderGroupPlan:
                                       drop_p=c.res_dropout if training else 0.0, drop_site=site(e.enc_id, top, S_RES2)))
         if fin:
             ops.ln_bwd(fin, d, self.dtype, seed)
-        self._run(self._bwd[training], seed)
+        # on_layer(i, events): every parameter gradient of layer i (and, with the first call, of the final LayerNorm)
+        # is complete once `events` have passed -- the data-parallel exchange starts there (distributed.GradSync)
+        self._run(self._bwd[training], seed, on_layer)
         p = c.embed_dropout if training else 0.0
         emb = []
         for e, b in zip(self.encs, self.buf):

@@ -393,8 +393,7 @@ class _Trunk:
         self._ready("fuse")
         for (tgt, name), t in self.tmap.items():
             d1[name] = t["dh"]
-        dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2])
-        self._ready("level2")
+        dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2], self._layer_hook("level2"))
         for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
             if self.prune:                   # the GMU terms only touch rows 0 and N-1 of the level-1 output
                 full = gk + gv
@@ -402,8 +401,7 @@ class _Trunk:
                 d1[src] = full
             else:
                 d1[src] = d1[src] + gk + gv
-        dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1])
-        self._ready("level1")
+        dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1], self._layer_hook("level1"))
         acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
             acc[q].append(gq)
@@ -420,12 +418,23 @@ class _Trunk:
         st.end_backward()
         return res
 
-    def _ready(self, section: str) -> None:
+    def _ready(self, section: str, events=None) -> None:
         hook = getattr(self.m, "_grad_ready_hook", None)
         if hook is not None:
             lo, hi = self.st.sections[section]
             if hi > lo:
-                hook(self.st.gflat, lo, hi)
+                hook(self.st.gflat, lo, hi, events)
+
+    def _layer_hook(self, tag: str):
+        if getattr(self.m, "_grad_ready_hook", None) is None:
+            return None
+        top = self.m.layers - 1
+
+        def on_layer(i: int, events) -> None:
+            if i == top:                                  # the final LayerNorm's gradients were written before layer top
+                self._ready(f"{tag}.final", events)
+            self._ready(f"{tag}.layer{i}", events)
+        return on_layer
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -508,10 +517,16 @@ class _BPMulTBase(nn.Module):
             allp = {n: p for n, p in self.named_parameters() if not n.startswith(self.TAIL)}
             # flat layout in reverse execution order, so a finished section of the gradient buffer
             # can be all-reduced while backward continues (distributed.GradSync)
-            secs = [("fuse", lambda n: n.startswith(("gmu_", "transfm_"))),
-                    ("level2", lambda n: n.split(".")[0] in LEVEL2),
-                    ("level1", lambda n: n.split(".")[0] in LEVEL1),
-                    ("proj", lambda n: n.startswith("proj_"))]
+            # ... at LAYER granularity inside a level: the six encoders run their layers in lock-step, so layer i
+            # of all six is one contiguous ~26 MB slice that is final ~2 layers after backward passes it
+            def lvl(names, tag):
+                out = [(f"{tag}.final", lambda n, names=names: n.split(".")[0] in names and n.split(".")[1] == "layer_norm")]
+                for i in reversed(range(self.layers)):
+                    out.append((f"{tag}.layer{i}", lambda n, names=names, i=i: n.split(".")[0] in names
+                                and n.split(".")[1] == "layers" and int(n.split(".")[2]) == i))
+                return out
+            secs = ([("fuse", lambda n: n.startswith(("gmu_", "transfm_")))] + lvl(LEVEL2, "level2") + lvl(LEVEL1, "level1")
+                    + [("proj", lambda n: n.startswith("proj_"))])
             named, bounds = [], []
             for sname, pred in secs:
                 part = [(n, p) for n, p in allp.items() if pred(n)]
