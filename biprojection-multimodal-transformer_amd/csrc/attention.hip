@@ -140,7 +140,7 @@ BPM_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_ex
 // forward
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? 4 : 1, DHP <= 32 ? 4 : 8))) void attn_fwd_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AGroup grp) {
 // backward, dQ (and delta = rowsum(dO * O))
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? 4 : 1, DHP <= 32 ? 4 : 8))) void attn_bwd_dq_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_bwd_dq_kernel(const AGroup grp)
 // backward, dK and dV
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) void attn_bwd_dkv_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? 4 : 1, DHP <= 32 ? 4 : 8))) void attn_bwd_dkv_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * QT * C::STRIDE + 2 * QT * 4];
