@@ -128,7 +128,7 @@ def main():
         dQ, dK, dV = (torch.zeros(R, ld, device=dev, dtype=ct) for _ in range(3))
         keep.extend([Q, K_, V, O, lse, delta, dO, dQ, dK, dV])
         aps.append(ops.attn_problem(Q, K_, V, O, ld, lse, B, H, N, N, dh, dhp, 1, dO=dO, delta=delta, dQ=dQ, lddq=ld, dK=dK, lddk=ld,
-                                    dV=dV, lddv=ld, dq_scale=dh ** -0.5, drop_p=0.1, drop_site=5))
+                                    dV=dV, lddv=ld, dq_scale=dh ** -0.5, drop_p=float(os.environ.get("ATTN_DROP", "0.1")), drop_site=5))
     arr = ops.array(ops.AttnProblem, aps)
     pairs = N * (N + 1) / 2
     timeit("attn fwd (causal, drop)", lambda: ops.attn_fwd(dt, arr, 3), 4.0 * pairs * dh * B * H * G)
