@@ -138,12 +138,32 @@ class ParamStore:
         return (self.params[n0].data_ptr() == self._master_ptr + 4 * self.off[n0]
                 and self.params[n1].data_ptr() == self._master_ptr + 4 * self.off[n1])
 
+    def prezero(self) -> None:
+        """Called at the start of a training forward: if the gradients are unset now (the usual zero_grad /
+        `p.grad = None` step), clear the flat gradient buffer on the side stream while the forward pass runs, instead
+        of on the critical path when backward starts."""
+        self._prezero_ev = None
+        if self.params[self.names[0]].grad is None and _SIDE:
+            main = torch.cuda.current_stream()
+            side = _side_stream(main.device)
+            side.wait_stream(main)                      # the previous step's consumers of gflat (optimizer, all-reduce)
+            with torch.cuda.stream(side):
+                self.gflat.zero_()
+            self._prezero_ev = torch.cuda.Event()
+            self._prezero_ev.record(side)
+
     def begin_backward(self) -> None:
         """Gradients accumulate into gflat like autograd accumulates into .grad:
         a parameter whose .grad is None starts from zero."""
         fresh = self.params[self.names[0]].grad is None
-        if fresh:
+        ev = getattr(self, "_prezero_ev", None)
+        self._prezero_ev = None
+        if fresh and ev is not None:
+            torch.cuda.current_stream().wait_event(ev)  # already cleared during the forward pass
+        elif fresh:
             self.gflat.zero_()
+        elif ev is not None:
+            raise RuntimeError("gradients were attached between forward and backward of one step")
 
     def end_backward(self) -> None:
         for n in self.names:
@@ -296,6 +316,19 @@ class EncoderGroupPlan:
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dev, dtype=dt)
         L = cfg.layers
         self.buf: List[dict] = []
+        # accumulators that every backward starts from zero (d(khat), d(vhat), folded bias sums): ONE buffer, one fill
+        nacc = sum(2 * (e.S * B * d + 16) + L * 2 * d + 16 for e in self.encs)
+        self._acc0 = torch.zeros(nacc, device=dev, dtype=torch.float32)
+        acc_off = [0]
+
+        def carve(*shape):
+            n = 1
+            for v in shape:
+                n *= v
+            t = self._acc0[acc_off[0]: acc_off[0] + n].view(*shape)
+            acc_off[0] += (n + 15) // 16 * 16
+            return t
+
         for e in self.encs:
             R, Rk = e.T * B, e.S * B
             b = dict(R=R, Rk=Rk)
@@ -307,9 +340,9 @@ class EncoderGroupPlan:
             # into the K / V projection weights, see register_encoder_shadows)
             b["khat"], b["vhat"] = z(Rk, self.ld, dt=ct), z(Rk, self.ld, dt=ct)
             b["stk"], b["stv"] = (z(Rk), z(Rk)), (z(Rk), z(Rk))
-            b["Gk"], b["Gv"] = z(Rk, d), z(Rk, d)                   # sum over layers of d(khat), d(vhat)
+            b["Gk"], b["Gv"] = carve(Rk, d), carve(Rk, d)           # sum over layers of d(khat), d(vhat)
             b["dWf"] = [z(2 * d, d) for _ in range(L)]              # folded K/V weight gradients (per backward)
-            b["dbf"] = z(L, 2 * d)                                  # folded K/V bias gradients (column sums)
+            b["dbf"] = carve(L, 2 * d)                              # folded K/V bias gradients (column sums)
             for nm, shape, dt in (("xn", (R, self.ld), ct),
                                   ("qh", (B, H, e.T, self.dhp), ct), ("kh", (B, H, e.S, self.dhp), ct),
                                   ("vh", (B, H, e.S, self.dhp), ct), ("ao", (R, self.ld), ct), ("lse", (B, H, e.T), torch.float32),
@@ -710,10 +743,8 @@ class EncoderGroupPlan:
         c, st, B, d = self.cfg, self.store, self.B, self.cfg.d
         fin, keep = [], []
         top = c.layers - 1
+        self._acc0.zero_()
         for e, b, g in zip(self.encs, self.buf, douts):
-            b["Gk"].zero_()
-            b["Gv"].zero_()
-            b["dbf"].zero_()
             if g is None:
                 b["dx"].zero_()
                 b["dyf"][top % 3].zero_()

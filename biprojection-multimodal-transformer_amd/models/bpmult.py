@@ -343,6 +343,8 @@ class _Trunk:
     # -- whole trunk ------------------------------------------------------------------
     def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> List[torch.Tensor]:
         self.st.refresh_shadows()
+        if training and getattr(self.m, "_want_grad", False):
+            self.st.prezero()
         self.conv_forward(feats, seed, training)
         px = self.px
         q1 = [px[q] for (q, kv, _) in LEVEL1.values()]
@@ -592,6 +594,7 @@ class _BPMulTBase(nn.Module):
 
     def _trunk(self, x_l, x_v, x_a):
         self._ensure_store()
+        self._want_grad = torch.is_grad_enabled()       # (grad mode is off inside autograd.Function.forward)
         return _TrunkFn.apply(self._anchor, x_l.float(), x_v.float(), x_a.float(), self)
 
 
