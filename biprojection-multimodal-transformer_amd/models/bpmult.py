@@ -446,12 +446,17 @@ class _TrunkFn(torch.autograd.Function):
         seed = model._next_seed()
         feats = {"l": x_l.detach().contiguous(), "v": x_v.detach().contiguous(), "a": x_a.detach().contiguous()}
         outs = trunk.forward(feats, seed, model.training)
-        ctx.trunk, ctx.seed = trunk, seed
+        trunk.stamp = getattr(trunk, "stamp", 0) + 1
+        ctx.trunk, ctx.seed, ctx.stamp = trunk, seed, trunk.stamp
         ctx.need = {"l": x_l.requires_grad, "v": x_v.requires_grad, "a": x_a.requires_grad}
         return tuple(o.detach().clone() for o in outs)
 
     @staticmethod
     def backward(ctx, *grads):
+        if ctx.stamp != ctx.trunk.stamp:
+            # activations live in per-batch-size buffers owned by the model, not in the autograd graph
+            raise RuntimeError("BPMulT hot path: backward() of a forward pass that a later forward pass (same model, same "
+                               "batch size) has overwritten; run forward -> backward one step at a time")
         res = ctx.trunk.backward(grads, ctx.seed, ctx.need)
         return None, res["l"], res["v"], res["a"], None
 

@@ -50,7 +50,8 @@ def _c_fields(struct_name):
 @pytest.mark.parametrize("cname,cls", [("bpm_gemm_problem", _lib.GemmProblem), ("bpm_attn_problem", _lib.AttnProblem),
                                        ("bpm_pack_problem", _lib.PackProblem), ("bpm_pack_desc", _lib.PackDesc),
                                        ("bpm_embed_problem", _lib.EmbedProblem), ("bpm_ln_problem", _lib.LnProblem),
-                                       ("bpm_cast_problem", _lib.CastProblem), ("bpm_gmu_problem", _lib.GmuProblem)])
+                                       ("bpm_cast_problem", _lib.CastProblem), ("bpm_gmu_problem", _lib.GmuProblem),
+                                       ("bpm_fold_desc", _lib.FoldDesc), ("bpm_unfold_desc", _lib.UnfoldDesc)])
 def test_ctypes_structs_mirror_the_header(cname, cls):
     assert _c_fields(cname) == [f[0] for f in cls._fields_]
 
@@ -68,6 +69,18 @@ def test_error_strings_and_argument_validation(lib):
     assert lib.bpm_ln_fwd(_lib.BPM_F32, C.byref(ln), 1, 300, 1e-5, None) == -1
     p.A, p.B, p.C, p.M, p.N, p.K, p.lda, p.ldb = 16, 16, 16, 4, 4, 4, 3, 32   # lda*2 bytes not a multiple of 16
     assert lib.bpm_gemm_grouped(_lib.BPM_BF16, _lib.GEMM_NT, C.byref(p), 1, 0, None) == -2
+    # later additions: every entry validates on the host before touching the device
+    assert lib.bpm_attn_bwd_dq(_lib.BPM_BF16, C.byref(a), 1, 0, None) == -1
+    assert lib.bpm_attn_bwd_dkv(_lib.BPM_BF16, C.byref(a), 1, 0, None) == -1
+    assert lib.bpm_ln_bwd(_lib.BPM_F32, C.byref(ln), 1, 300, 0, None) == -1
+    assert lib.bpm_fold_bias(None, 1, 1, None) == -1 and lib.bpm_unfold_grads(None, 1, 1, None) == -1
+    assert lib.bpm_adam_step(None, None, None, None, 16, 1e-3, .9, .999, 1e-8, 0., 1, 1., 0, None) == -1
+    assert lib.bpm_adam_step(16, 16, 16, 16, 6, 1e-3, .9, .999, 1e-8, 0., 1, 1., 0, None) == -1     # n % 4
+    assert lib.bpm_adam_step(16, 16, 16, 20, 8, 1e-3, .9, .999, 1e-8, 0., 1, 1., 0, None) == -2     # alignment
+    assert lib.bpm_adam_step(16, 16, 16, 16, 8, 1e-3, .9, .999, 1e-8, 0., 0, 1., 0, None) == -1     # step >= 1
+    assert lib.bpm_stream_create(1, None) == -1
+    e = _lib.EmbedProblem()
+    assert lib.bpm_embed_pos_bwd(C.byref(e), 1, 24, 1.0, 0, None) == -1
 
 
 def test_no_cpu_fallback():

@@ -220,3 +220,14 @@ def test_pruned_level2_schedule_is_exact(prec):
         assert rel(g1, g0) <= tol_g, (k, rel(g1, g0))
     for g0, g1 in zip(outs[0][3], outs[1][3]):
         assert rel(g1, g0) <= tol_g
+
+
+def test_stale_backward_raises():
+    m = get_model(args_for("mmtrvat", hidden_sz=24, num_heads=4, layers=1, orig_d_l=32, num_vectors_l=32, num_vectors_a=32,
+                           num_vectors_v=32)).cuda().train()
+    x = [torch.randn(2, 10, 32, device="cuda"), torch.randn(2, 20, 35, device="cuda"), torch.randn(2, 30, 74, device="cuda")]
+    l1 = m(x[0], None, None, x[1], x[2]).sum()
+    l2 = m(x[0], None, None, x[1], x[2]).sum()
+    with pytest.raises(RuntimeError, match="one step at a time"):
+        l1.backward()
+    l2.backward()
