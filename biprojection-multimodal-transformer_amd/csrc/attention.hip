@@ -211,15 +211,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
         const float alpha = fast_exp2((m_run - m_new) * LOG2E);
         const float mneg = -m_new * LOG2E;
         m_run = m_new;
-        float psum = 0.f;
+        // 4-wide float arithmetic compiles to packed-f32 VALU (v_pk_fma_f32 / v_pk_add_f32: two lanes of work per
+        // instruction); only the exponentials stay scalar
+        f32x4 ps4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n) {
+            const f32x4 e4 = st[n] * LOG2E + mneg;
+            f32x4 p4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(fmaf(st[n][r], LOG2E, mneg));
-                psum += p;
-                st[n][r] = p;
-            }
+            for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
+            ps4 += p4;
+            st[n] = p4;
+        }
+        const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         if (dropping) {
             if (pair_ok) {                             // wave-uniform: (r, r+1) share one hash
 #pragma unroll
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
                     float d0, d1, d2, d3;
                     bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n), d0, d1);
                     bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n + 2), d2, d3);
-                    st[n][0] *= d0; st[n][1] *= d1; st[n][2] *= d2; st[n][3] *= d3;
+                    st[n] *= f32x4{d0, d1, d2, d3};
                 }
             } else {
 #pragma unroll
@@ -352,13 +356,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
                     for (int r = 0; r < 4; ++r) dm[r] = bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
                 }
             }
+            f32x4 e4 = s_ * LOG2E + lse2;
+            if (edge) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float e = fmaf(s_[r], LOG2E, lse2);
-                if (edge) e = (16 * n + r < rel) ? e : -INFINITY;      // exp2(-inf) = 0: masked before the exponential
-                const float p = fast_exp2(e);
-                ds[n][r] = p * (dp[r] * dm[r] - delta);
+                for (int r = 0; r < 4; ++r) e4[r] = (16 * n + r < rel) ? e4[r] : -INFINITY;   // exp2(-inf) = 0: masked before the exponential
             }
+            f32x4 p4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
+            const f32x4 dm4 = f32x4{dm[0], dm[1], dm[2], dm[3]};
+            ds[n] = p4 * (dp * dm4 - delta);
         }
         // dQ^T += K^T dS^T
 #pragma unroll
@@ -463,16 +470,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
             const f32x4 l4 = *(const f32x4*)(s_lse + 16 * u + 4 * g);
             const f32x4 d4 = *(const f32x4*)(s_del + 16 * u + 4 * g);
             const int ib = qt * QT + 16 * u + 4 * g;       // query of element r is ib + r
+            f32x4 e4 = s_ * LOG2E + l4;
+            if (edge) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float e = fmaf(s_[r], LOG2E, l4[r]);
-                if (edge) e = (ib + r >= ilo && ib + r < P.T) ? e : -INFINITY;
-                const float p = fast_exp2(e);
-                float dm = 1.f;
-                if (dropping) dm = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
-                pd[u][r] = p * dm;
-                ds[u][r] = p * (dp[r] * dm - d4[r]);
+                for (int r = 0; r < 4; ++r) e4[r] = (ib + r >= ilo && ib + r < P.T) ? e4[r] : -INFINITY;
             }
+            f32x4 p4, dm4 = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
+            if (dropping) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dm4[r] = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
+            }
+            pd[u] = p4 * dm4;
+            ds[u] = p4 * (dp * dm4 - d4);
         }
 #pragma unroll
         for (int ks = 0; ks < QT / Tr<CT>::KSTEP; ++ks) {
