@@ -63,10 +63,11 @@ constexpr int TN = BN / WN / 16;          // 2 along n
 // 64-byte k-steps per LDS stage of the tiled kernel.  Measured on MI355X at the model's shapes: the
 // forward / dgrad GEMMs with short k loops are latency bound and the smaller stage (12 KB, 5 workgroups
 // per CU) wins by 25-50 %; the weight-gradient GEMM (K = T*B rows) prefers the longer stage.
-// waves per SIMD the tiled kernel is compiled for (register budget 512 / BPM_TILED_MINW per lane): 4 keeps the
-// two-phase epilogue's operand registers without spilling; 5 spills
+// waves per SIMD the tiled kernel is compiled for (register budget 512 / BPM_TILED_MINW per lane): 5 fits without
+// spilling since the epilogue no longer keeps a per-row offset table (84-88 VGPRs); 6 spills and runs 1.3-1.8x slower.
+// Measured: 4 and 5 perform the same (the kernel is not occupancy-bound), so the extra wave is free headroom.
 #ifndef BPM_TILED_MINW
-#define BPM_TILED_MINW 4
+#define BPM_TILED_MINW 5
 #endif
 #ifndef BPM_DEEP_TN
 #define BPM_DEEP_TN 2
@@ -278,7 +279,9 @@ BPM_DEV EpiRow epi_row(const Prob& P, int m) {
 // Interleaving them per tile (load, compute, store, load, ...) serialises one memory round trip per tile, because
 // the loads may alias the stores and cannot be hoisted by the compiler: measured 6.6 us of a 16 us workgroup.
 template <typename CT, int NB>
-BPM_DEV void epilogue_fast(const Prob& P, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB], f32x4& csum) {
+BPM_DEV void epilogue_fast(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NB], f32x4& csum) {
+    // rows mrow + 16*b: their offsets are recomputed where needed (a few multiplies) instead of living in a 24-register
+    // table through the whole epilogue -- the table was what pushed the kernel past the 4 -> 5 waves/SIMD budget
     const bool colok = nb < P.N;                        // N % 4 == 0: a lane's 4 columns are all in or all out
     const uint32_t nbc = colok ? (uint32_t)nb : 0u;     // clamped column for the loads
     const bool f32out = P.out_kind == BPM_OUT_F32;
@@ -291,17 +294,17 @@ BPM_DEV void epilogue_fast(const Prob& P, int nb, const f32x4 (&acc)[NB], const 
     if (P.bias_n) bias = *(const f32x4*)(P.bias_n + nbc);
     if (P.gate) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) gt[b] = *(const gate_t*)((const CT*)P.gate + rows[b].offg + nbc);
+        for (int b = 0; b < NB; ++b) gt[b] = *(const gate_t*)((const CT*)P.gate + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldg + nbc);
     } else {
 #pragma unroll
         for (int b = 0; b < NB; ++b) gt[b] = gate_t{};
     }
     if (P.resid) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)(P.resid + rows[b].offr + nbc);
+        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)(P.resid + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldr + nbc);
     } else if (accum) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)((const float*)P.C + rows[b].offc + nbc);
+        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)((const float*)P.C + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldc + nbc);
     } else {
 #pragma unroll
         for (int b = 0; b < NB; ++b) addv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -309,7 +312,7 @@ BPM_DEV void epilogue_fast(const Prob& P, int nb, const f32x4 (&acc)[NB], const 
 
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const EpiRow& e = rows[b];
+        const EpiRow e = epi_row(P, mrow + 16 * b);
         const bool valid = e.ok && colok;
         f32x4 x = acc[b];
         if (valid) {
@@ -358,7 +361,7 @@ template <typename CT, int NB>
 BPM_DEV void epilogue_cols(const Prob& P, bool fast, bool lead, int m0, int r, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB]) {
     if (fast) {
         f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-        epilogue_fast<CT, NB>(P, nb, acc, rows, cs);
+        epilogue_fast<CT, NB>(P, m0 + r, nb, acc, cs);
         if (P.colsum) { float c4[4] = {cs[0], cs[1], cs[2], cs[3]}; flush_colsum(P, c4, nb, r); }
     } else {
         float csum[4] = {0.f, 0.f, 0.f, 0.f};
