@@ -231,3 +231,69 @@ def test_stale_backward_raises():
     with pytest.raises(RuntimeError, match="one step at a time"):
         l1.backward()
     l2.backward()
+
+
+def _toy(seed=3, **kw):
+    torch.manual_seed(seed)
+    a = args_for("mmtrvat", hidden_sz=24, num_heads=4, layers=2, orig_d_l=32, num_vectors_l=48, num_vectors_a=48,
+                 num_vectors_v=48, **kw)
+    m = get_model(a)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    m.precision = "f32"
+    return m
+
+
+def _toy_inputs(B=2, seed=4):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, 17, 32, generator=g).cuda(), torch.randn(B, 48, 35, generator=g).cuda(), torch.randn(B, 31, 74, generator=g).cuda()]
+
+
+def test_eval_mode_no_grad_and_state_dict_round_trip():
+    """eval() under no_grad (train.py:174) == train() with all dropout rates 0; a state_dict round trip into a fresh
+    model (the reference checkpoint format) reproduces the logits; .to() after a forward rebuilds the flat store."""
+    m = _toy().cuda()
+    x = _toy_inputs()
+    m.train()
+    ref = m(x[0], None, None, x[1], x[2]).detach()
+    m.eval()
+    with torch.no_grad():
+        out = m(x[0], None, None, x[1], x[2])
+    assert float((out - ref).abs().max()) <= 1e-5
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m2 = _toy(seed=99)
+    m2.load_state_dict(sd)
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        out2 = m2(x[0], None, None, x[1], x[2])
+    assert float((out2 - ref).abs().max()) <= 1e-5
+    m2 = m2.cpu().cuda()                                    # storages replaced: the store must be rebuilt
+    with torch.no_grad():
+        out3 = m2(x[0], None, None, x[1], x[2])
+    assert float((out3 - ref).abs().max()) <= 1e-5
+
+
+def test_gradient_accumulation_and_batch_of_one():
+    """Two backward passes without clearing .grad accumulate (train.py:390-398 gradient accumulation); batch size 1."""
+    m = _toy().cuda().train()
+    x = _toy_inputs(B=2)
+    tgt = (torch.randn(2, 6, generator=torch.Generator().manual_seed(1)) > 0).float().cuda()
+    lossf = torch.nn.functional.binary_cross_entropy_with_logits
+
+    def grads(sl, clear):
+        if clear:
+            for p in m.parameters():
+                p.grad = None
+        lossf(m(x[0][sl], None, None, x[1][sl], x[2][sl]), tgt[sl], reduction="sum").backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    full = grads(slice(0, 2), True)
+    grads(slice(0, 1), True)
+    acc = grads(slice(1, 2), False)                         # accumulates onto the first sample's gradients
+    for k in full:
+        n = float(full[k].abs().max())
+        if n < 1e-9:
+            continue
+        assert float((acc[k] - full[k]).abs().max()) <= 2e-4 * n + 1e-7, k
