@@ -157,7 +157,9 @@ def attn_ref(q, k, v, off, pmask):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("B,H,T,S,dh,masked,pdrop", [(2, 3, 70, 100, 25, True, 0.0), (1, 2, 130, 130, 25, True, 0.2),
                                                       (2, 2, 100, 70, 6, True, 0.0), (1, 2, 50, 50, 128, True, 0.0),
-                                                      (1, 1, 33, 65, 64, False, 0.1), (1, 2, 2, 200, 25, True, 0.0)])
+                                                      (1, 1, 33, 65, 64, False, 0.1), (1, 2, 2, 200, 25, True, 0.0),
+                                                      (1, 1, 1, 1, 25, True, 0.0), (3, 1, 1, 5, 8, True, 0.0),
+                                                      (1, 2, 513, 512, 25, True, 0.0)])
 def test_attention_fwd_bwd(dtype, B, H, T, S, dh, masked, pdrop):
     dhp = 32 if dh <= 32 else (64 if dh <= 64 else 128)
     ctt = ops.ct_torch(dtype)
