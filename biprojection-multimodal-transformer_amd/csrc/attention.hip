@@ -38,6 +38,9 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int KT = 64;      // keys per tile (forward / dQ)
+#ifndef BPM_ATTN_SETPRIO
+#define BPM_ATTN_SETPRIO 1
+#endif
 #ifndef BPM_ATTN_QT
 #define BPM_ATTN_QT 32
 #endif
@@ -244,6 +247,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
 #pragma unroll
         for (int n = 0; n < C::ND; ++n) o[n] *= alpha;
         // O^T += V^T Pd^T : k = keys of this tile
+#if BPM_ATTN_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
             const frag pf = Tr<CT>::pack_rows(st, ks);
@@ -251,6 +257,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
             for (int n = 0; n < C::ND; ++n)
                 o[n] = Tr<CT>::mma(Tr<CT>::read_tr(vimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, o[n]);
         }
+#if BPM_ATTN_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
@@ -368,6 +377,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
             ds[n] = p4 * (dp * dm4 - delta);
         }
         // dQ^T += K^T dS^T
+#if BPM_ATTN_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
             const frag df = Tr<CT>::pack_rows(ds, ks);
@@ -375,6 +387,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
             for (int n = 0; n < C::ND; ++n)
                 dq[n] = Tr<CT>::mma(Tr<CT>::read_tr(kimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dq[n]);
         }
+#if BPM_ATTN_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     if (q < P.T) {
         CT* row = (CT*)P.dQ + ((size_t)q * P.B + b) * P.lddq + h * P.dh;
@@ -486,6 +501,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
             pd[u] = p4 * dm4;
             ds[u] = p4 * (dp * dm4 - d4);
         }
+#if BPM_ATTN_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < QT / Tr<CT>::KSTEP; ++ks) {
             const frag pf = Tr<CT>::pack_rows(pd, ks);
@@ -496,6 +514,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
                 dk[n] = Tr<CT>::mma(Tr<CT>::read_tr(qimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dk[n]);
             }
         }
+#if BPM_ATTN_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     if (j < P.S) {
         CT* krow = (CT*)P.dK + ((size_t)j * P.B + b) * P.lddk + h * P.dh;

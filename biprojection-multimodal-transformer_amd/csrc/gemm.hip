@@ -69,6 +69,11 @@ constexpr int TN = BN / WN / 16;          // 2 along n
 #ifndef BPM_TILED_MINW
 #define BPM_TILED_MINW 5
 #endif
+// s_setprio(1) around the MFMA cluster: alone the GEMMs gain 1-10 % (wgrad 85 -> 80 us), inside the training step they
+// then take issue slots from the critical-path kernels of the other stream and the step gets SLOWER (17.0 -> 17.4 ms)
+#ifndef BPM_SETPRIO
+#define BPM_SETPRIO 0
+#endif
 #ifndef BPM_DEEP_TN
 #define BPM_DEEP_TN 2
 #endif
@@ -554,10 +559,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
             for (int b = 0; b < TM; ++b) fx[b] = SX::frag(ix, wm * (BM / WM) + 16 * b, ks, lane);
 #pragma unroll
             for (int a = 0; a < TN; ++a) fy[a] = SY::frag(iy, wn * (BN / WN) + 16 * a, ks, lane);
+#if BPM_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TM; ++b) acc[a][b] = Tr<CT>::mma(fy[a], fx[b], acc[a][b]);
+#if BPM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     };
 
