@@ -25,7 +25,7 @@ PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd
 BPM_F32, BPM_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
-F_ACCUM, F_RELU, F_ATOMIC, F_KPAD = 1, 2, 4, 8     # F_KPAD = BPM_GEMM_KPAD_ZERO
+F_ACCUM, F_RELU, F_ATOMIC, F_KPAD, F_BACKGROUND = 1, 2, 4, 8, 16     # F_KPAD = BPM_GEMM_KPAD_ZERO
 LN_OUT_F32 = 2
 MAX_GROUP = 18
 

@@ -38,6 +38,9 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int KT = 64;      // keys per tile (forward / dQ)
+#ifndef BPM_BASE_PRIO
+#define BPM_BASE_PRIO 1      // see gemm.hip
+#endif
 #ifndef BPM_ATTN_SETPRIO
 #define BPM_ATTN_SETPRIO 1
 #endif
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
     char* kimg = smem;
     char* vimg = smem + KT * C::STRIDE;
 
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
     const int bh = bid / P.nblk, qb = bid % P.nblk;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
         for (int n = 0; n < C::ND; ++n) o[n] *= alpha;
         // O^T += V^T Pd^T : k = keys of this tile
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
 #endif
 #pragma unroll
         for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
                 o[n] = Tr<CT>::mma(Tr<CT>::read_tr(vimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, o[n]);
         }
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
 #endif
     }
     l_run += __shfl_xor(l_run, 16);
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
     char* kimg = smem;
     char* vimg = smem + KT * C::STRIDE;
 
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
     const int bh = bid / P.nblk, qb = bid % P.nblk;
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
         }
         // dQ^T += K^T dS^T
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
 #endif
 #pragma unroll
         for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
                 dq[n] = Tr<CT>::mma(Tr<CT>::read_tr(kimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dq[n]);
         }
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
 #endif
     }
     if (q < P.T) {
@@ -416,6 +421,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
     float* s_lse = (float*)(smem + 2 * QT * C::STRIDE);      // -lse * log2(e)
     float* s_del = s_lse + QT;
 
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
     const int bh = bid / P.nblk, kb = bid % P.nblk;
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
             ds[u] = p4 * (dp * dm4 - d4);
         }
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
 #endif
 #pragma unroll
         for (int ks = 0; ks < QT / Tr<CT>::KSTEP; ++ks) {
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
             }
         }
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
 #endif
     }
     if (j < P.S) {

@@ -14,6 +14,10 @@
 #include "bpm_common.h"
 #include "../../include/bpmult_hip.h"
 
+#ifndef BPM_BASE_PRIO
+#define BPM_BASE_PRIO 1      // see gemm.hip
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -348,6 +352,7 @@ BPM_DEV float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 template <typename CT, int NV>
 __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const Grp<LnP> grp, int d, float eps) {
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     unsigned bid = blockIdx.x, nblk;
     const LnP& P = pick(grp, bid, nblk);
     const int lane = threadIdx.x & 63;
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const Grp<LnP> grp, int 
 
 template <typename CT, int NV>
 __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int d) {
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     __shared__ float red[3][NT / 64][NV * 256];
     unsigned bid = blockIdx.x, nblk;
     const LnP& P = pick(grp, bid, nblk);

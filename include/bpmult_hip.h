@@ -57,7 +57,10 @@ enum { BPM_OUT_F32 = 0, BPM_OUT_CT = 1, BPM_OUT_HEADS = 2 };
 /* BPM_GEMM_KPAD_ZERO: the caller promises that every row of a k-contiguous operand (A of NT/NN, B of NT) is
  * readable up to its leading dimension and holds ZEROS in [K, ld) -- what every CT buffer written by this
  * library satisfies.  It lets the kernel use hardware-bounded buffer loads with no k-tail masking. */
-enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4, BPM_GEMM_KPAD_ZERO = 8 };
+/* BPM_GEMM_BACKGROUND: this product is off the caller's critical path (weight gradients, work put on a side
+ * stream).  Forward / data-gradient products otherwise raise their waves' issue priority (s_setprio) so that, when
+ * kernels of two streams share a CU, the critical-path kernel is served first. */
+enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4, BPM_GEMM_KPAD_ZERO = 8, BPM_GEMM_BACKGROUND = 16 };
 
 typedef struct bpm_gemm_problem {
     const void* A;          /* CT */
