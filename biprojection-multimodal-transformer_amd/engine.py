@@ -32,8 +32,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
-from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,
-                   AttnProblem, CastProblem, EmbedProblem, FoldDesc, GemmProblem, GmuProblem, LnProblem, PackDesc, PackProblem,
+from ._lib import (F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
+                   AttnProblem, CastProblem, FoldDesc, GemmProblem, LnProblem, PackDesc,
                    UnfoldDesc)
 from .ops import pad32
 
@@ -273,10 +273,6 @@ class GroupCfg:
     embed_dropout: float
     attn_mask: bool
     biprojection: bool
-
-
-def _splitk(tiles_total: int, k: int) -> int:
-    return max(1, min(k // 512, 1024 // max(1, tiles_total), 16))
 
 
 SIDE, JOIN, MARK, WAIT = "side", "join", "mark", "wait"

@@ -18,9 +18,7 @@ zero-padding is device agnostic; `--hybrid` is not supported (broken upstream).
 """
 from __future__ import annotations
 
-import math
 import os
-from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -28,8 +26,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import config, ops
-from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, OUT_F32, CastProblem, GemmProblem, GmuProblem
-from ..engine import (SITE_TEXT, EncoderDesc, EncoderGroupPlan, GroupCfg, ParamStore, _splitk, register_encoder_shadows)
+from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, CastProblem, GemmProblem, GmuProblem
+from ..engine import SITE_TEXT, EncoderDesc, EncoderGroupPlan, GroupCfg, ParamStore, register_encoder_shadows
 from ..ops import pad32
 from .encoder import TransformerEncoder
 
