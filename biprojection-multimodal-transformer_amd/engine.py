@@ -275,23 +275,24 @@ class GroupCfg:
     biprojection: bool
 
 
-SIDE, JOIN, MARK, WAIT = "side", "join", "mark", "wait"
+SIDE, JOIN, MARK, WAIT, SIDE2 = "side", "join", "mark", "wait", "side2"
 _SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
-_DKV_SIDE = os.environ.get("BPMULT_DKV_SIDE", "0") == "1"
-_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+_DKV_SIDE = os.environ.get("BPMULT_DKV_SIDE", "0")       # "1": dK/dV pass on the side stream, "2": on a third stream
+_side_streams: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
+def _side_stream(device, which: int = 1) -> "torch.cuda.Stream":
     """One side stream per device, created through the C ABI at the device's LOWEST priority (the dispatcher
     then fills CUs from the main stream first); BPMULT_SIDE_PRIORITY=normal keeps the default priority."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    dev_i = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_i, which)
     if key not in _side_streams:
         from . import _lib
         low = os.environ.get("BPMULT_SIDE_PRIORITY", "low") != "normal"
         out = C.c_void_p()
-        with torch.cuda.device(key):
+        with torch.cuda.device(dev_i):
             _lib.check(_lib.lib().bpm_stream_create(int(low), C.byref(out)), "bpm_stream_create")
-        _side_streams[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key))
+        _side_streams[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", dev_i))
     return _side_streams[key]
 
 
@@ -537,7 +538,7 @@ class EncoderGroupPlan:
                     on_mark(s[1], [ev])
                 if s is JOIN or s[0] is MARK or s[0] is WAIT:
                     continue
-                self._exec(s[1] if s[0] is SIDE else s, seed)
+                self._exec(s[1] if s[0] in (SIDE, SIDE2) else s, seed)
             return
         main = torch.cuda.current_stream()
         side = _side_stream(main.device)
@@ -550,6 +551,17 @@ class EncoderGroupPlan:
                     ev.record(side)
                     main.wait_event(ev)
                     side_dirty = False
+            elif s[0] is SIDE2:                     # third stream: starts right behind the main stream's last launch
+                side2 = _side_stream(main.device, 2)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side2.wait_event(ev)
+                with torch.cuda.stream(side2):
+                    self._exec(s[1], seed)
+                ev2 = torch.cuda.Event()
+                ev2.record(side2)
+                side.wait_event(ev2)                # the side stream's later steps consume its output
+                side_dirty = True
             elif s[0] is SIDE:
                 if main_dirty:
                     ev = torch.cuda.Event()
@@ -704,8 +716,8 @@ class EncoderGroupPlan:
                       (ops.attn_bwd_dq, self.dtype, A(AttnProblem, att)),
                       # dK / dV feed only side work, but running their pass beside the main chain measured SLOWER
                       # (17.7 -> 18.7 ms/step: the side stream becomes the longer one); opt-in for experiments
-                      ((SIDE, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))) if _DKV_SIDE
-                       else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
+                      ((SIDE if _DKV_SIDE == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
+                       if _DKV_SIDE in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
                       (SIDE, (ops.rows_cast, self.dtype, A(CastProblem, csum))),
                       (SIDE, self._gemm(GEMM_TN, wg_att, background=True)),
                       (SIDE, self._gemm(GEMM_NN, dg_kv)),
