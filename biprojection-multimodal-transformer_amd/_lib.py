@@ -55,7 +55,7 @@ class GemmProblem(C.Structure):
                 ("colsum", C.c_void_p),
                 ("flags", C.c_int), ("out_kind", C.c_int), ("splitk", C.c_int),
                 ("heads_B", C.c_int), ("heads_H", C.c_int), ("heads_T", C.c_int),
-                ("heads_dh", C.c_int), ("heads_dhp", C.c_int)]
+                ("heads_dh", C.c_int), ("heads_dhp", C.c_int), ("colsum_a", C.c_void_p)]
 
 
 class AttnProblem(C.Structure):

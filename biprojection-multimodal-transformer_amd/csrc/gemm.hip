@@ -109,6 +109,7 @@ struct Prob {
     float alpha;
     DropCfg drop;
     float* colsum;
+    float* colsum_x;      // TN: [M] += sum_k X[k, m]
     int flags;
     int out_kind;
     int hB, hH, hT, hdh, hdhp;
@@ -526,7 +527,7 @@ __device__ unsigned long long g_trace[8192 * 16];
 #endif
 
 template <typename CT, bool XK, bool YK, int KSTEPS, bool DEEP = false, bool FAST = false>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TILED_MINW, BPM_TILED_MINW))) void gemm_tiled_kernel(const Group grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK && !YK) ? 4 : BPM_TILED_MINW, (!XK && !YK) ? 4 : BPM_TILED_MINW))) void gemm_tiled_kernel(const Group grp) {
     typedef Side<CT, XK, BM, KSTEPS, XK && !YK> SX;     // NN: X is k-contiguous beside a transposed-read Y
     typedef Side<CT, YK, BN, KSTEPS, false> SY;
     constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
@@ -556,6 +557,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // TN only: column sums of X (bias gradient beside a weight gradient) in the workgroups of the first N tile, by the
+    // waves of the first wave column: one MFMA per X fragment against an operand of ones
+    [[maybe_unused]] f32x4 xs[TM];
+    [[maybe_unused]] bool do_xs = false;
+    if constexpr (!XK && !YK) {
+        do_xs = P.colsum_x != nullptr && n0 == 0 && wn == 0;       // wave-uniform
+#pragma unroll
+        for (int b = 0; b < TM; ++b) xs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     auto compute = [&](const char* ix) {
         const char* iy = ix + SX::IMG_BYTES;
 #pragma unroll
@@ -563,6 +573,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
             typename Tr<CT>::frag fx[TM], fy[TN];
 #pragma unroll
             for (int b = 0; b < TM; ++b) fx[b] = SX::frag(ix, wm * (BM / WM) + 16 * b, ks, lane);
+            if constexpr (!XK && !YK) {
+                if (do_xs) {
+                    typename Tr<CT>::frag one;
+#pragma unroll
+                    for (int j = 0; j < Tr<CT>::EPC; ++j) one[j] = Tr<CT>::from_f(1.0f);
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) xs[b] = Tr<CT>::mma(one, fx[b], xs[b]);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < TN; ++a) fy[a] = SY::frag(iy, wn * (BN / WN) + 16 * a, ks, lane);
 #if BPM_SETPRIO
@@ -666,6 +685,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BPM_TI
 
     const int r = lane & 15, g = lane >> 4;
     const bool lead = (split == 0);
+    if constexpr (!XK && !YK) {
+        if (do_xs && g == 0) {               // every row of the ones-product holds the sums: lane r has column m
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * (BM / WM) + 16 * b + r;
+                if (m < P.M) P.colsum_x[m] += xs[b][0];
+            }
+        }
+    }
     if (kt_lo >= kt_hi && !lead) return;
     const bool fast = epi_fast_ok(P);                   // wave-uniform
     const int mw = m0 + wm * (BM / WM);
@@ -913,6 +941,8 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         p.alpha = q.alpha;
         p.drop = bpm_make_drop(q.drop_p, seed, q.drop_site);
         p.colsum = q.colsum;
+        p.colsum_x = q.colsum_a;
+        if (q.colsum_a && (variant != BPM_GEMM_TN || q.splitk > 1)) return BPM_ERR_ARG;
         p.flags = q.flags; p.out_kind = q.out_kind;
         p.hB = q.heads_B; p.hH = q.heads_H; p.hT = q.heads_T; p.hdh = q.heads_dh; p.hdhp = q.heads_dhp;
         if (q.out_kind == BPM_OUT_HEADS && (q.heads_B < 1 || q.heads_dh < 1 || q.heads_H * q.heads_dh != q.N)) return BPM_ERR_ARG;

@@ -617,8 +617,8 @@ class EncoderGroupPlan:
         inv_relu = 1.0 / (1.0 - pr(c.relu_dropout))
         for i in reversed(range(c.layers)):
             wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], []
-            wg_att, dg_out, att, csum, dg_q, dg_kv, lnq = [], [], [], [], [], [], []
-            s_cast0, s_dgout0, s_att0, s_csum0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], [], []
+            wg_att, dg_out, att, dg_q, dg_kv, lnq = [], [], [], [], [], []
+            s_cast0, s_dgout0, s_att0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], []
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
                 P = lambda leaf: st.p(self._pn(e, i, leaf))
@@ -664,13 +664,12 @@ class EncoderGroupPlan:
                 # query projection: gradients go straight to the parameters.  Key / value projections ran with the
                 # LayerNorm folded in: their bias column sums and weight gradients (against khat / vhat) land in
                 # per-layer scratch and are unfolded into in_proj / LayerNorm gradients by one launch at the end.
-                csum.append(ops.cast_problem(dq, ld, R, d, a_is_ct=True, colsum=st.gptr(ipb_g, 0)))
-                csum.append(ops.cast_problem(dk, ld, Rk, d, a_is_ct=True, colsum=b["dbf"][i][:d]))
-                csum.append(ops.cast_problem(dv, ld, Rk, d, a_is_ct=True, colsum=b["dbf"][i][d:]))
+                # (the bias column sums ride on the weight-gradient GEMMs: colsum_a, one extra MFMA against ones)
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
-                wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, R, ld, ld, d, flags=F_ACCUM))
-                wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ld, ld, d))
-                wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ld, ld, d))
+                wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, R, ld, ld, d, flags=F_ACCUM,
+                                               colsum_a=st.gptr(ipb_g, 0)))
+                wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ld, ld, d, colsum_a=b["dbf"][i][:d]))
+                wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ld, ld, d, colsum_a=b["dbf"][i][d:]))
                 if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
                     dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
                 else:
@@ -694,8 +693,8 @@ class EncoderGroupPlan:
                                                    lddq=ld, dK=dks, lddk=ld, dV=dvs, lddv=ld, dq_scale=self.scale,
                                                    drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
                     for w, src in ((0, dqs), (1, dks), (2, dvs)):
-                        s_csum0.append(ops.cast_problem(src, ld, R, d, a_is_ct=True, colsum=st.gptr(ipb_g, w * d)))
-                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, ld, ld, d, flags=F_ACCUM))
+                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, ld, ld, d, flags=F_ACCUM,
+                                                      colsum_a=st.gptr(ipb_g, w * d)))
                     # d(xn) = dq Wq + dk Wk + dv Wv: three launches (plain store, then two +=) -- one owner per
                     # output tile in each launch, no atomics (per-lane-scattered float atomics run ~17x below store rate)
                     s_dg0a.append(ops.gemm_problem(dqs, st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
@@ -718,7 +717,6 @@ class EncoderGroupPlan:
                       # (17.7 -> 18.7 ms/step: the side stream becomes the longer one); opt-in for experiments
                       ((SIDE if _DKV_SIDE == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
                        if _DKV_SIDE in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
-                      (SIDE, (ops.rows_cast, self.dtype, A(CastProblem, csum))),
                       (SIDE, self._gemm(GEMM_TN, wg_att, background=True)),
                       (SIDE, self._gemm(GEMM_NN, dg_kv)),
                       self._gemm(GEMM_NN, dg_q)]
@@ -728,7 +726,6 @@ class EncoderGroupPlan:
                 steps += [(ops.rows_cast, self.dtype, A(CastProblem, s_cast0)),
                           self._gemm(GEMM_NN, s_dgout0),
                           (ops.attn_bwd, self.dtype, A(AttnProblem, s_att0)),
-                          (SIDE, (ops.rows_cast, self.dtype, A(CastProblem, s_csum0))),
                           (SIDE, self._gemm(GEMM_TN, s_wg0, background=True)),
                           self._gemm(GEMM_NN, s_dg0a),
                           self._gemm(GEMM_NN, s_dg0b),

@@ -67,7 +67,7 @@ def _as_array(cls, probs):
 def gemm_problem(A, B, Cc, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, bias_n=None, bias_m=None,
                  resid=None, ldr: int = 0, gate=None, ldg: int = 0, gate_scale: float = 1.0, alpha: float = 1.0,
                  drop_p: float = 0.0, drop_site: int = 0, colsum=None, flags: int = 0, out_kind: int = OUT_F32,
-                 splitk: int = 1, heads=None) -> GemmProblem:
+                 splitk: int = 1, heads=None, colsum_a=None) -> GemmProblem:
     """A, B, C: tensors or raw device addresses (int).  heads = (B, H, T, dh, dhp) for OUT_HEADS."""
     p = GemmProblem()
     p.A, p.B, p.C = (x if isinstance(x, int) else _p(x) for x in (A, B, Cc))
@@ -81,6 +81,7 @@ def gemm_problem(A, B, Cc, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
     p.flags, p.out_kind, p.splitk = flags, out_kind, splitk
     if heads is not None:
         p.heads_B, p.heads_H, p.heads_T, p.heads_dh, p.heads_dhp = heads
+    p.colsum_a = colsum_a if isinstance(colsum_a, int) else _f32(colsum_a, "colsum_a")
     return p
 
 

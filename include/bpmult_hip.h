@@ -84,6 +84,10 @@ typedef struct bpm_gemm_problem {
     int splitk;             /* >1 needs BPM_GEMM_ATOMIC + BPM_OUT_F32 into a zeroed / accumulating buffer */
     /* BPM_OUT_HEADS: row m = t*B + b, column n = h*dh + c  ->  C[b][h][t][c] of [B,H,T,dhp] */
     int heads_B, heads_H, heads_T, heads_dh, heads_dhp;
+    /* BPM_GEMM_TN only: colsum_a[m] += sum_k A[k, m] (the bias gradient that belongs to a weight gradient
+     * dW = dY^T X: A = dY), taken from the operand tiles already in registers by one extra MFMA against a vector
+     * of ones in the workgroups of the first N tile.  Needs splitk == 1.  NULL = off. */
+    float* colsum_a;
 } bpm_gemm_problem;
 
 int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs /* host */, int nprob,

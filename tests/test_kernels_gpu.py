@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from bpmult_amd import ops  # noqa: E402
-from bpmult_amd.ops import (BPM_BF16, BPM_F32, F_ATOMIC, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,  # noqa: E402
+from bpmult_amd.ops import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_F32, OUT_HEADS,  # noqa: E402
                             pad32)
 
 DEV = "cuda"
@@ -502,3 +502,22 @@ def test_gathered_query_rows_keep_positions():
     ops.embed_pos_fwd([ops.embed_problem(x.to(DEV), full, T2, 3)], table, d, math.sqrt(d), seed=0)
     ops.embed_pos_fwd([ops.embed_problem(xg, part, 2, 3, pos0=0, pos_stride=T2 - 1)], table, d, math.sqrt(d), seed=0)
     close(part, full[[0, T2 - 1]].cpu(), 1e-6, "gathered embed_pos")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_tn_colsum_of_first_operand(dtype):
+    """colsum_a: the bias gradient beside a weight gradient (column sums of A over the contraction rows), += semantics,
+    ragged M / N, two problems in one launch."""
+    probs, keep, refs = [], [], []
+    for (M, N, K, s0) in ((300, 140, 1000, 70), (77, 300, 333, 72)):
+        A, Ar = to_ct(rnd(K, M, seed=s0), dtype)
+        Bm, Br = to_ct(rnd(K, N, seed=s0 + 1, scale=K ** -0.5), dtype)
+        out = torch.zeros(M, N, device=DEV)
+        cs = torch.ones(M, device=DEV)
+        keep += [A, Bm, out, cs]
+        refs.append((Ar.double().T @ Br.double(), 1 + Ar.double().sum(0)))
+        probs.append(ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N, flags=F_ACCUM if s0 == 70 else 0, colsum_a=cs))
+    ops.gemm_grouped(dtype, GEMM_TN, probs)
+    for i, (rc, rs) in enumerate(refs):
+        close(keep[4 * i + 2], rc, tol(dtype) if dtype == BPM_F32 else 2e-3, "tn product")
+        close(keep[4 * i + 3], rs, 1e-4 if dtype == BPM_F32 else 2e-3, "colsum_a")
