@@ -701,11 +701,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
 #pragma unroll
     for (int b = 0; b < TM; ++b) rows[b] = epi_row(P, mw + 16 * b + r);
     BPM_TRACE(12);
-#pragma unroll
-    for (int a = 0; a < TN; ++a) {     // colsum shuffles: uniform per workgroup, every lane takes part
-        epilogue_cols<CT, TM>(P, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows);
-        BPM_TRACE(13 + a);
-    }
+    // (explicitly unrolled: a rolled loop would index the accumulators dynamically and send them to scratch)
+    auto epi = [&](auto A) {           // colsum shuffles: uniform per workgroup, every lane takes part
+        constexpr int a = decltype(A)::value;
+        if constexpr (a < TN) {
+            epilogue_cols<CT, TM>(P, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows);
+            BPM_TRACE(13 + a);
+        }
+    };
+    epi(std::integral_constant<int, 0>{}); epi(std::integral_constant<int, 1>{});
+    epi(std::integral_constant<int, 2>{}); epi(std::integral_constant<int, 3>{});
+    static_assert(TN <= 4, "epilogue unrolled for up to 4 column tiles per wave");
 #ifdef BPM_GEMM_TRACE
     __builtin_amdgcn_s_waitcnt(0);     // stores issued; vmcnt drained
     BPM_TRACE(15);
