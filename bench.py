@@ -43,6 +43,9 @@ CONFIGS = {
     "cfg3": dict(model="mmtrvapt", hidden_sz=768, num_heads=6, layers=5, n_classes=13, orig_d_l=768, orig_d_v=4096, orig_d_a=96,
                  orig_d_p=4096, L=512, V=200, A=1000, nv=(512, 200, 200), batch=8,
                  desc="Moviescope-shape synthetic 4-modal mmtrvapt d=768 H=6 layers=5 L=512 V=A=200"),
+    "h768": dict(model="mmtrvat", hidden_sz=768, num_heads=12, layers=8, n_classes=6, orig_d_l=768, orig_d_v=35, orig_d_a=74,
+                 orig_d_p=4096, L=20, V=500, A=400, nv=(512, 512, 512), batch=8,
+                 desc="the metric text read literally: IEMOCAP-shape 3-modal unaligned mmtrvat at hidden 768 (H=12 layers=8, ->512)"),
     "k768": dict(model="mmtrvat", hidden_sz=768, num_heads=6, layers=5, n_classes=6, orig_d_l=768, orig_d_v=35, orig_d_a=74,
                  orig_d_p=4096, L=50, V=50, A=50, nv=(50, 50, 50), batch=64,
                  desc="kernel point: 3-modal d=768 H=6 layers=5 seq_len=50"),
