@@ -21,6 +21,8 @@ of the reference arithmetic) on a bounded sample of the same workload.
 `value` is always the reference's DENSE schedule; `pruned_schedule` is a second,
 separately timed figure for the exact dead-row elimination of SURVEY.md A.10
 (same logits and gradients, fewer executed flops) and is never the headline.
+`hidden768_3modal` (default run on one GPU only) times the same 3-modal unaligned
+shape at hidden 768 -- the metric string read literally; see DESIGN.md section 7.
 """
 import argparse
 import ctypes as C
@@ -167,6 +169,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pruned", action="store_true", help="skip the secondary measurement of the pruned schedule")
+    ap.add_argument("--no-h768", action="store_true", help="skip the secondary hidden-768 figure (default config, 1 GPU only)")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1)
     a = ap.parse_args()
@@ -284,6 +287,34 @@ def main():
     torch.cuda.synchronize()
     opt_ms = (time.perf_counter() - t1) / 3 * 1e3
 
+    # Secondary figure, never `value`: the metric text read literally (same 3-modal unaligned shape at hidden 768).
+    h768 = None
+    if world == 1 and a.config == "cfg1" and not a.no_h768 and not a.batch and a.precision == "bf16":
+        del model, opt, sync
+        torch.cuda.empty_cache()
+        c8 = CONFIGS["h768"]
+        m8 = get_model(model_args(c8, a.precision)).to(dev).train()
+        b8 = synth_batch(c8, c8["batch"], 1234, dev)
+
+        def step8():
+            for p in m8.parameters():
+                p.grad = None
+            crit(run_model(m8, b8), b8["tgt"]).backward()
+
+        for _ in range(2):
+            step8()
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        n8 = min(a.steps, 10)
+        for _ in range(n8):
+            step8()
+        torch.cuda.synchronize()
+        d8 = time.perf_counter() - t8
+        h768 = {"value": round(c8["batch"] * n8 / d8, 3), "unit": "samples/s", "ms_per_step": round(d8 / n8 * 1e3, 3),
+                "steps": n8, "workload": c8["desc"]}
+        del m8, b8
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ach = work.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         traffic = hbm_traffic(dom) if (a.config == "cfg1" and a.precision == "bf16" and not a.batch) else None
@@ -303,6 +334,8 @@ def main():
         }
         if pruned is not None:
             out["pruned_schedule"] = pruned
+        if h768 is not None:
+            out["hidden768_3modal"] = h768
         print("[bench] gpu part done: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline")}), file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, a.cpu_batch, a.cpu_steps)
