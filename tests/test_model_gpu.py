@@ -297,3 +297,15 @@ def test_gradient_accumulation_and_batch_of_one():
         if n < 1e-9:
             continue
         assert float((acc[k] - full[k]).abs().max()) <= 2e-4 * n + 1e-7, k
+
+
+def test_input_longer_than_num_vectors_is_rejected():
+    """The reference zero-pads to fixed lengths (mmtr.py:431-441) and would silently mis-shape longer inputs; here it
+    is an error before anything is launched."""
+    m = _toy().cuda().eval()
+    x = _toy_inputs()
+    too_long = torch.randn(2, 49, 35, device="cuda")          # num_vectors_v = 48
+    with torch.no_grad(), pytest.raises(ValueError, match="exceeds num_vectors"):
+        m(x[0], None, None, too_long, x[2])
+    with torch.no_grad():                                      # exactly the maximum is fine
+        m(x[0], None, None, torch.randn(2, 48, 35, device="cuda"), x[2])
