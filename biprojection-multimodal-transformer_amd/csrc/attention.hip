@@ -38,6 +38,9 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int KT = 64;      // keys per tile (forward / dQ)
+#ifndef BPM_ATTN_W128
+#define BPM_ATTN_W128 2    // waves per SIMD at head_dim 128 (unified 256-register budget: no AGPR copies)
+#endif
 #ifndef BPM_ATTN_WF
 #define BPM_ATTN_WF 5      // waves per SIMD of the forward kernel at head_dim <= 32 (90 VGPRs; dQ / dKdV spill at 5)
 #endif
@@ -149,7 +152,7 @@ BPM_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_ex
 // forward
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? BPM_ATTN_WF : 1, DHP <= 32 ? BPM_ATTN_WF : 8))) void attn_fwd_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? BPM_ATTN_WF : (DHP <= 64 ? 4 : (sizeof(CT) == 2 ? 3 : 2)), DHP <= 32 ? BPM_ATTN_WF : (DHP <= 64 ? 4 : (sizeof(CT) == 2 ? 3 : 2))))) void attn_fwd_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
 // backward, dQ (and delta = rowsum(dO * O))
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? 4 : 1, DHP <= 32 ? 4 : 8))) void attn_bwd_dq_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 64 ? 4 : BPM_ATTN_W128, DHP <= 64 ? 4 : BPM_ATTN_W128))) void attn_bwd_dq_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
 // backward, dK and dV
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? 4 : 1, DHP <= 32 ? 4 : 8))) void attn_bwd_dkv_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 64 ? 4 : BPM_ATTN_W128, DHP <= 64 ? 4 : BPM_ATTN_W128))) void attn_bwd_dkv_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * QT * C::STRIDE + 2 * QT * 4];
