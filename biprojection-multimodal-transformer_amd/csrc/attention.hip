@@ -51,7 +51,7 @@ constexpr int KT = 64;      // keys per tile (forward / dQ)
 #define BPM_ATTN_SETPRIO 1
 #endif
 #ifndef BPM_ATTN_QT
-#define BPM_ATTN_QT 32
+#define BPM_ATTN_QT 64
 #endif
 constexpr int QT = BPM_ATTN_QT;      // queries per tile (dK/dV): a multiple of 32
 constexpr float LOG2E = 1.4426950408889634f;
