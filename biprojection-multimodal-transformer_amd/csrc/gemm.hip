@@ -20,17 +20,10 @@
 //   conflict free for ds_read_b128's lane groups, k-strided operands as
 //   [k][rows] images read transposed (ds_read_b64_tr_b16 / ds_read_b32).
 //
-// * gemm_astat_kernel -- "A stationary", for NT / NN products whose whole K
-//   extent is at most 640 bytes per row (hidden size 300 in bf16: every
-//   projection, fc1 and their data gradients).  Ablations of the tiled kernel
-//   at those shapes (tools/bench_kernels.py) showed the time
-//   going to per-workgroup fixed cost and the epilogue, not to MFMA or loads:
-//   with K = 300 a tile has only 5-10 k-iterations.  Here a wave loads its 32
-//   rows of A ONCE, straight into registers as MFMA operand chunks (80 VGPRs),
-//   and the workgroup then walks a range of N tiles, streaming only the weight
-//   tile (L2 resident) through a double-buffered LDS image and running the
-//   epilogue per N tile: 5-19x fewer workgroups, A read once, one barrier per
-//   128 x 64 x K block of MFMAs instead of one per 32 of k.
+// * gemm_dma_kernel (gemm_dma.h) -- bf16 products with k extents of whole 128-byte stages and at least
+//   one full 128 x 128 tile (hidden >= 512: every encoder GEMM at hidden 768 / 1536).  128 x 128 or 256 x 128
+//   tile, each wave 64 x 64, operands moved global -> LDS by `buffer_load ... lds` into a ring of stages that
+//   stays in flight across barriers (counted vmcnt), 64 k per stage.
 //
 // The MFMA is issued "swapped" (Y rows as the A operand, X rows as the B
 // operand) so that a lane owns 4 consecutive n of one output row m and the
@@ -92,13 +85,6 @@ constexpr int TN = BN / WN / 16;          // 2 along n
 #define BPM_KS_WGRAD 2
 #endif
 constexpr int KS_FWD = BPM_KS_FWD, KS_WGRAD = BPM_KS_WGRAD;
-// A-stationary kernel: up to 10 k-steps (640 bytes of k per row) held in registers
-constexpr int AS_KS = 10;
-constexpr int AS_BM = 128;                // 4 waves x 32 rows
-// N tile of the streamed weight image: the k-strided (NN) image is [320 k][N tile], so it takes the narrower tile
-// to keep two buffers within 60 KB (two workgroups per CU)
-constexpr int AS_BN_NT = 64, AS_BN_NN = 32;
-
 struct Prob {
     const char* X; const char* Y; char* C;
     int M, N, K;
@@ -113,8 +99,8 @@ struct Prob {
     int flags;
     int out_kind;
     int hB, hH, hT, hdh, hdhp;
-    int tile0, tiles_m, tiles_n, splitk;   // astat: tiles_n = N tiles per workgroup, splitk = number of N ranges
-    int splitk_is_one;                     // no split-K (always true for the A-stationary kernel)
+    int tile0, tiles_m, tiles_n, splitk;
+    int splitk_is_one;                     // no split-K
 };
 
 struct Group {
@@ -719,156 +705,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// A-stationary kernel (NT / NN with K*sizeof(CT) <= 640)
-// ---------------------------------------------------------------------------
-template <typename CT, bool YK, int ABN>
-struct AsW {                                   // LDS image of one weight tile: ABN n-rows (or columns) x all of K
-    static constexpr int SZ = sizeof(CT);
-    static constexpr int EPC = Tr<CT>::EPC;
-    static constexpr int KROWS = AS_KS * Tr<CT>::KSTEP;                       // k elements held
-    // YK: [ks][n][64 B] swizzled sub-images (4 KB per k-step);  !YK: [k][ABN*sz + pad] for transposed reads
-    static constexpr int TSTRIDE = ABN * SZ + Tr<CT>::TR_PAD_B;
-    static constexpr int IMG_BYTES = YK ? AS_KS * ABN * 64 : KROWS * TSTRIDE;
-    static constexpr int NCHUNK = YK ? AS_KS * ABN * 4 : KROWS * (ABN * SZ / 16);
-    static constexpr int PER_THREAD = (NCHUNK + NTHREADS - 1) / NTHREADS;
-
-    static BPM_DEV void load(const Prob& P, int n0, int nks, u32x4 (&reg)[PER_THREAD], int tid) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * NTHREADS;
-            bool ok = c < NCHUNK;
-            size_t off;
-            if (YK) {                       // chunk c -> k-step ks, row n, 16-byte chunk kc of W[n][k]
-                const int ks = c / (ABN * 4), rem = c % (ABN * 4);
-                const int n = rem >> 2, kc = rem & 3;
-                const int k = ks * Tr<CT>::KSTEP + kc * EPC;
-                ok = ok && (ks < nks) && (n0 + n < P.N) && (k < P.K);
-                off = ((size_t)(n0 + n) * P.ldy + k) * SZ;
-            } else {                        // chunk c -> k row kr, 16-byte chunk cc of B[k][n]
-                constexpr int CPR = ABN * SZ / 16;
-                const int kr = c / CPR, cc = c % CPR;
-                const int col = n0 + cc * EPC;
-                ok = ok && (kr < P.K) && (col + EPC <= P.ldy) && (col < P.N);
-                off = ((size_t)kr * P.ldy + col) * SZ;
-            }
-            reg[i] = ok ? *(const u32x4*)(P.Y + off) : u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    static BPM_DEV void store(char* img, const u32x4 (&reg)[PER_THREAD], int tid) {
-#pragma unroll
-        for (int i = 0; i < PER_THREAD; ++i) {
-            const int c = tid + i * NTHREADS;
-            if (c >= NCHUNK) continue;
-            int dst;
-            if (YK) {
-                const int ks = c / (ABN * 4), rem = c % (ABN * 4);
-                const int n = rem >> 2, kc = rem & 3;
-                dst = ks * (ABN * 64) + n * 64 + ((kc ^ swz4(n)) << 4);
-            } else {
-                constexpr int CPR = ABN * SZ / 16;
-                dst = (c / CPR) * TSTRIDE + (c % CPR) * 16;
-            }
-            *(u32x4*)(img + dst) = reg[i];
-        }
-    }
-    static BPM_DEV typename Tr<CT>::frag frag(const char* img, int n0w, int ks, int lane) {
-        if (YK) {
-            const int r = lane & 15, g = lane >> 4;
-            return *(const typename Tr<CT>::frag*)(img + ks * (ABN * 64) + (n0w + r) * 64 + ((g ^ swz4(n0w + r)) << 4));
-        }
-        return Tr<CT>::read_tr(img, TSTRIDE, ks * Tr<CT>::KSTEP, n0w, lane, Tr<CT>::TR_CTILE);
-    }
-};
-
-// A operand chunk of k-step ks for row `row`, straight from global memory.  Beside a transposed-read
-// weight image (NN, bf16) the chunk holds k = 4g..4g+3 and 16+4g..16+4g+3 (two 8-byte loads) so that
-// element order matches the "ctile" order of the other operand.
-template <typename CT, bool YK>
-BPM_DEV typename Tr<CT>::frag load_a_chunk(const Prob& P, int row, int ks, int g) {
-    typedef typename Tr<CT>::frag frag;
-    if (row >= P.M || ks * Tr<CT>::KSTEP >= P.K) return Tr<CT>::zero();
-    const char* base = P.X + ((size_t)row * P.ldx) * sizeof(CT) + ks * 64;
-    if constexpr (!YK && sizeof(CT) == 2) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 lo = *(const u32x2*)(base + g * 8), hi = *(const u32x2*)(base + 32 + g * 8);
-        u32x4 v = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        return *(frag*)&v;
-    } else {
-        return *(const frag*)(base + g * 16);
-    }
-}
-
-template <typename CT, bool YK, int ABN>
-__global__ __launch_bounds__(NTHREADS) void gemm_astat_kernel(const Group grp) {
-    typedef AsW<CT, YK, ABN> W;
-    typedef typename Tr<CT>::frag frag;
-    __shared__ __attribute__((aligned(16))) char smem[2 * W::IMG_BYTES];
-    constexpr int MT = AS_BM / 4 / 16;          // 2 m-tiles (32 rows) per wave
-    constexpr int NTW = ABN / 16;               // every wave covers the whole N tile
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const Prob& P = pick_problem(grp, bid);
-    const int mt = bid / P.splitk, ns = bid % P.splitk;
-    const int m0 = mt * AS_BM + wave * 32;
-    const int ntiles = (P.N + ABN - 1) / ABN;
-    const int nt_lo = ns * P.tiles_n, nt_hi = min(ntiles, nt_lo + P.tiles_n);
-    const int nks = (P.K + Tr<CT>::KSTEP - 1) / Tr<CT>::KSTEP;
-
-    // the wave's rows of A, once, as MFMA operand chunks
-    frag fa[MT][AS_KS];
-#pragma unroll
-    for (int b = 0; b < MT; ++b)
-#pragma unroll
-        for (int ks = 0; ks < AS_KS; ++ks) fa[b][ks] = load_a_chunk<CT, YK>(P, m0 + 16 * b + r, ks, g);
-
-    const bool fast = epi_fast_ok(P);
-    EpiRow rows[MT];
-#pragma unroll
-    for (int b = 0; b < MT; ++b) rows[b] = epi_row(P, m0 + 16 * b + r);
-
-    u32x4 rw[W::PER_THREAD];
-    if (nt_lo < nt_hi) {
-        W::load(P, nt_lo * ABN, nks, rw, tid);
-        W::store(smem, rw, tid);
-    }
-    __syncthreads();
-    int cur = 0;
-#pragma unroll 1
-    for (int nt = nt_lo; nt < nt_hi; ++nt) {
-        const bool more = nt + 1 < nt_hi;
-        if (more) W::load(P, (nt + 1) * ABN, nks, rw, tid);
-        const char* img = smem + cur * W::IMG_BYTES;
-        f32x4 acc[NTW][MT];
-#pragma unroll
-        for (int a = 0; a < NTW; ++a)
-#pragma unroll
-            for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < AS_KS; ++ks) {
-            if (ks < nks) {
-#pragma unroll
-                for (int a = 0; a < NTW; ++a) {
-                    const frag fy = W::frag(img, 16 * a, ks, lane);
-#pragma unroll
-                    for (int b = 0; b < MT; ++b) acc[a][b] = Tr<CT>::mma(fy, fa[b][ks], acc[a][b]);
-                }
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < NTW; ++a) epilogue_cols<CT, MT>(P, fast, true, m0, r, nt * ABN + 16 * a + 4 * g, acc[a], rows);
-        if (more) W::store(smem + (cur ^ 1) * W::IMG_BYTES, rw, tid);
-        __syncthreads();
-        cur ^= 1;
-    }
-}
+#include "gemm_dma.h"
 
 template <typename CT>
-int launch(int variant, bool astat, bool fast, bool bm64, const Group& g, hipStream_t s) {
+int launch(int variant, bool fast, bool bm64, const Group& g, hipStream_t s) {
     dim3 grid(g.total_tiles), block(NTHREADS);
-    if (!astat && fast) {
+    if (fast) {
         switch (variant) {
             case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD, BPM_DEEP_FWD != 0, true>), grid, block, 0, s, g); break;
             case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, 1, BPM_DEEP_FWD != 0, true>), grid, block, 0, s, g); break;
@@ -881,28 +723,61 @@ int launch(int variant, bool astat, bool fast, bool bm64, const Group& g, hipStr
         BPM_CHECK_LAUNCH();
         return 0;
     }
-    if (astat) {
-        if (variant == BPM_GEMM_NT) hipLaunchKernelGGL((gemm_astat_kernel<CT, true, AS_BN_NT>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_astat_kernel<CT, false, AS_BN_NN>), grid, block, 0, s, g);
-    } else {
-        switch (variant) {
-            case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD, BPM_DEEP_FWD != 0>), grid, block, 0, s, g); break;
-            case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, 1, BPM_DEEP_FWD != 0>), grid, block, 0, s, g); break;
-            case BPM_GEMM_TN:
-                // measured (MI355X, K = 4096 rows): with at least ~2 workgroups per CU the short stage wins
-                // (more resident workgroups hide the load latency); below that the long stage does
-                if (g.total_tiles >= 2 * 256) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1, BPM_DEEP_TN != 0>), grid, block, 0, s, g);
-                else if (BPM_DEEP_TN == 2) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1, true>), grid, block, 0, s, g);
-                else hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, KS_WGRAD, false>), grid, block, 0, s, g);
-                break;
-            default: return BPM_ERR_ARG;
-        }
+    switch (variant) {
+        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, true, KS_FWD, BPM_DEEP_FWD != 0>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_tiled_kernel<CT, true, false, 1, BPM_DEEP_FWD != 0>), grid, block, 0, s, g); break;
+        case BPM_GEMM_TN:
+            // measured (MI355X, K = 4096 rows): with at least ~2 workgroups per CU the short stage wins
+            // (more resident workgroups hide the load latency); below that the long stage does
+            if (g.total_tiles >= 2 * 256) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1, BPM_DEEP_TN != 0>), grid, block, 0, s, g);
+            else if (BPM_DEEP_TN == 2) hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, 1, true>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_tiled_kernel<CT, false, false, KS_WGRAD, false>), grid, block, 0, s, g);
+            break;
+        default: return BPM_ERR_ARG;
     }
     BPM_CHECK_LAUNCH();
     return 0;
 }
 
+// LDS-DMA kernel configurations: (waves along m, waves along n, m tiles per wave, stages)
+template <int WMD, int WND, int TMW, int NS>
+int launch_dma_cfg(int variant, const Group& g, hipStream_t s) {
+    dim3 grid(g.total_tiles), block(64 * WMD * WND);
+    switch (variant) {
+        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_dma_kernel<true, true, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_dma_kernel<true, false, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
+        case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
+        default: return BPM_ERR_ARG;
+    }
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+struct DmaCfg { int bm, bn; };
+constexpr DmaCfg DMA_CFGS[] = {{128, 128}, {256, 128}, {256, 256}, {256, 256}, {128, 128}};
+constexpr int N_DMA_CFGS = sizeof(DMA_CFGS) / sizeof(DMA_CFGS[0]);
+
+int launch_dma(int cfg, int variant, const Group& g, hipStream_t s) {
+    switch (cfg) {
+        case 0: return launch_dma_cfg<2, 2, 4, 2>(variant, g, s);      // 128 x 128,  4 waves, 2 stages (64 KB: 2 per CU)
+        case 1: return launch_dma_cfg<4, 2, 4, 2>(variant, g, s);      // 256 x 128,  8 waves
+        case 2: return launch_dma_cfg<2, 4, 8, 2>(variant, g, s);      // 256 x 256,  8 waves of 128 x 64
+        case 3: return launch_dma_cfg<4, 4, 4, 2>(variant, g, s);      // 256 x 256, 16 waves of 64 x 64
+        case 4: return launch_dma_cfg<2, 2, 4, 3>(variant, g, s);      // 128 x 128,  3 stages
+    }
+    return BPM_ERR_ARG;
+}
+
+// tuning hook (tools/gemm_lab.py): -1 = automatic choice, -2 = never the LDS-DMA kernel, 0.. = force DMA_CFGS[i] where legal
+int g_force_dma = -1;
+
 }  // namespace
+
+extern "C" int bpm_debug_gemm_force(int cfg) {
+    if (cfg < -2 || cfg >= N_DMA_CFGS) return BPM_ERR_ARG;
+    g_force_dma = cfg;
+    return 0;
+}
 
 #ifdef BPM_GEMM_TRACE
 extern "C" int bpm_debug_trace(unsigned long long* out, int nblocks) {
@@ -915,27 +790,12 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
     if (variant != BPM_GEMM_NT && variant != BPM_GEMM_NN && variant != BPM_GEMM_TN) return BPM_ERR_ARG;
     const int sz = dtype == BPM_BF16 ? 2 : 4;
-    // A-stationary path: every problem of the launch has its whole K in 10 k-steps and no split-K
-    bool astat = variant != BPM_GEMM_TN;
-    long rows = 0;
-    for (int i = 0; i < nprob; ++i) {
-        if ((long)probs[i].K * sz > AS_KS * 64 || probs[i].splitk > 1 || (probs[i].flags & BPM_GEMM_ATOMIC)) astat = false;
-        rows += probs[i].M;
-    }
-    if (astat && rows < 1024) astat = false;       // tiny launches: nothing to amortise
-    // Measured on MI355X (tools/bench_kernels.py, hidden 300, B*T = 4096 x 6 problems): the A-stationary kernel is
-    // correct (the parity suite runs it in f32 and bf16 with BPM_ASTAT=1) but 1.3-2x SLOWER than the tiled kernel:
-    // both are bound by the exposed memory latency of a depth-1 prefetch, and the tiled kernel hides it with 5
-    // workgroups per CU where this one has 2.  It stays opt-in until its weight stream is prefetched deeper.
-    static const bool use_astat = getenv("BPM_ASTAT") != nullptr;
-    if (!use_astat) astat = false;
+    const bool xk = variant != BPM_GEMM_TN, yk = variant == BPM_GEMM_NT;
     // hardware-bounded loader: every problem promises zero k padding, k-contiguous rows are whole k stages and the
     // matrices fit 31-bit byte offsets
-    static const bool no_fast = getenv("BPM_NO_FASTLD") != nullptr;
-    bool fast = !no_fast;
+    bool fast = true;
     for (int i = 0; i < nprob && fast; ++i) {
         const bpm_gemm_problem& q = probs[i];
-        const bool xk = variant != BPM_GEMM_TN, yk = variant == BPM_GEMM_NT;
         const int stage_b = 64 * (variant == BPM_GEMM_NT ? KS_FWD : 1);
         fast = (q.flags & BPM_GEMM_KPAD_ZERO) != 0;
         if (xk) fast = fast && ((long)q.lda * sz) % stage_b == 0 && (long)q.K <= q.lda;
@@ -943,10 +803,29 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         const long bx = (long)(xk ? q.M : q.K) * q.lda * sz, by = (long)(yk ? q.N : q.K) * q.ldb * sz;
         fast = fast && bx < (1l << 31) - 65536 && by < (1l << 31) - 65536;
     }
+    // LDS-DMA kernel (gemm_dma.h): bf16, no split-K, k-contiguous operands hold whole 128-byte stages inside their
+    // zero-padded rows.  Chosen (256 x 256 tiles) for the FFN-sized products -- measured on MI355X at hidden 768
+    // (tools/gemm_lab.py): fc1 265 -> 162 us, its data gradient 311 -> 270, FFN weight gradients 443 -> 408; the
+    // K = N = 768 products stay on the 128 x 64 kernel, whose 5 workgroups per CU overlap epilogues with main loops.
+    int dma = -1;
+    if (dtype == BPM_BF16 && fast && g_force_dma != -2) {
+        bool legal = true, big = true;
+        for (int i = 0; i < nprob && legal; ++i) {
+            const bpm_gemm_problem& q = probs[i];
+            const long kceil = ((long)q.K + DK - 1) / DK * DK;
+            legal = q.splitk <= 1 && !(q.flags & BPM_GEMM_ATOMIC) && (!xk || kceil <= q.lda) && (!yk || kceil <= q.ldb);
+            const long tm = (q.M + 255) / 256, tn = (q.N + 255) / 256;
+            big = big && q.M >= 256 && q.N >= 256 && q.K >= 256 && (q.N >= 1024 || q.K >= 1024) &&
+                  (double)q.M * q.N >= 0.8 * (double)(tm * 256) * (double)(tn * 256);
+        }
+        if (legal && g_force_dma >= 0) dma = g_force_dma;
+        else if (legal && big) dma = variant == BPM_GEMM_TN ? 2 : 3;
+    }
     // under-filled weight-gradient launches (fewer than two 128-row workgroups per CU) run 64-row workgroups:
     // measured 98 -> 77 us for the 24 attention weight gradients of a layer (360 -> 600 workgroups)
-    int bm_tile = BM;
-    if (variant == BPM_GEMM_TN && fast && !astat && BM == 128) {
+    int bm_tile = BM, bn_tile = BN;
+    if (dma >= 0) { bm_tile = DMA_CFGS[dma].bm; bn_tile = DMA_CFGS[dma].bn; }
+    else if (variant == BPM_GEMM_TN && fast && BM == 128) {
         long t128 = 0;
         for (int i = 0; i < nprob; ++i)
             t128 += (long)((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN) * (probs[i].splitk > 1 ? probs[i].splitk : 1);
@@ -955,9 +834,6 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     Group g;
     g.nprob = nprob;
     int tile = 0;
-    // N tiles per workgroup of the A-stationary kernel: enough ranges that the launch has >= ~512 workgroups
-    long mtiles = 0;
-    for (int i = 0; i < nprob; ++i) mtiles += (probs[i].M + AS_BM - 1) / AS_BM;
     for (int i = 0; i < nprob; ++i) {
         const bpm_gemm_problem& q = probs[i];
         Prob& p = g.p[i];
@@ -979,33 +855,22 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         p.flags = q.flags; p.out_kind = q.out_kind;
         p.hB = q.heads_B; p.hH = q.heads_H; p.hT = q.heads_T; p.hdh = q.heads_dh; p.hdhp = q.heads_dhp;
         if (q.out_kind == BPM_OUT_HEADS && (q.heads_B < 1 || q.heads_dh < 1 || q.heads_H * q.heads_dh != q.N)) return BPM_ERR_ARG;
-        const int bn = astat ? (variant == BPM_GEMM_NT ? AS_BN_NT : AS_BN_NN) : BN;
-        const int ntiles = (q.N + bn - 1) / bn;
-        if (q.out_kind == BPM_OUT_CT && ntiles * bn < q.ldc) return BPM_ERR_ARG;
+        const int ntiles = (q.N + bn_tile - 1) / bn_tile;
+        if (q.out_kind == BPM_OUT_CT && ntiles * bn_tile < q.ldc) return BPM_ERR_ARG;
         p.tile0 = tile;
-        if (astat) {
-            p.tiles_m = (q.M + AS_BM - 1) / AS_BM;
-            int ranges = (int)((512 + mtiles - 1) / mtiles);
-            if (ranges > ntiles) ranges = ntiles;
-            if (ranges < 1) ranges = 1;
-            p.tiles_n = (ntiles + ranges - 1) / ranges;           // N tiles per workgroup
-            p.splitk = (ntiles + p.tiles_n - 1) / p.tiles_n;      // number of N ranges
-            p.splitk_is_one = 1;
-            tile += p.tiles_m * p.splitk;
-        } else {
-            p.tiles_m = (q.M + bm_tile - 1) / bm_tile;
-            p.tiles_n = ntiles;
-            p.splitk = q.splitk > 1 ? q.splitk : 1;
-            p.splitk_is_one = p.splitk == 1;
-            if (p.splitk > 1 && !((q.flags & BPM_GEMM_ATOMIC) && q.out_kind == BPM_OUT_F32)) return BPM_ERR_ARG;
-            tile += p.tiles_m * p.tiles_n * p.splitk;
-        }
+        p.tiles_m = (q.M + bm_tile - 1) / bm_tile;
+        p.tiles_n = ntiles;
+        p.splitk = q.splitk > 1 ? q.splitk : 1;
+        p.splitk_is_one = p.splitk == 1;
+        if (p.splitk > 1 && !((q.flags & BPM_GEMM_ATOMIC) && q.out_kind == BPM_OUT_F32)) return BPM_ERR_ARG;
+        tile += p.tiles_m * p.tiles_n * p.splitk;
     }
     g.total_tiles = tile;
     hipStream_t s = (hipStream_t)stream;
     double flops = 0;
     for (int i = 0; i < nprob; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * probs[i].K;
     BpmProfScope prof(BPM_K_GEMM_NT + variant, s, flops);
-    return dtype == BPM_BF16 ? launch<bf16_t>(variant, astat, fast, bm_tile == 64, g, s)
-                             : launch<float>(variant, astat, fast, bm_tile == 64, g, s);
+    if (dma >= 0) return launch_dma(dma, variant, g, s);
+    return dtype == BPM_BF16 ? launch<bf16_t>(variant, fast, bm_tile == 64, g, s)
+                             : launch<float>(variant, fast, bm_tile == 64, g, s);
 }

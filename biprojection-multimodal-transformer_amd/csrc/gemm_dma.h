@@ -1,0 +1,250 @@
+// LDS-DMA grouped GEMM for the hidden >= 512 shapes (bf16 operands, f32 accumulate).  Included by gemm.hip inside
+// its anonymous namespace, after Prob / Group / the shared epilogue.
+//
+// Why a second kernel: at hidden 768 a step is ~18 TFLOP of GEMM whose k extents are 768 / 3072 / 4096.  The
+// register-staged 128 x 64 kernel (gemm_tiled_kernel) was built for K = 300 (5-10 k iterations, latency bound,
+// 5 workgroups per CU); at these sizes it spends its time staging: 64-byte half-line global loads, a ds_write pass
+// per stage and 6 KB of LDS reads per 8 MFMAs.  This kernel
+//   * computes a 128 x 128 ... 256 x 256 tile per workgroup, every wave a 64 x 64 or 128 x 64 block of MFMA 16x16x32
+//     tiles (16 ds_read_b128 per 32 MFMAs / 24 per 64: at most half the LDS bytes per flop of the 128 x 64 kernel;
+//     the vector-memory path of a CU moves 64 B per clock, so a 128 x 128 x 64 stage costs as many clocks to load as
+//     its MFMAs take at peak and only the 256-wide tiles can run the matrix pipe above ~50 %),
+//   * moves both operands global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write pass), 64 k per
+//     stage so that a k-contiguous row contributes one whole 128-byte line per stage,
+//   * keeps NS stages in a ring: the loads of stage kt+NS-1 are issued right after the barrier that retires stage kt
+//     and stay in flight across barriers (counted `s_waitcnt vmcnt(N)`, raw `s_barrier`: a `__syncthreads()` would
+//     drain them), one barrier per k stage,
+//   * shares the epilogue (bias, ReLU, gate, dropout, residual, column sums, f32 / CT / head-major stores) with the
+//     tiled kernel: same swapped-operand MFMA, so a lane again owns 4 consecutive n of one output row.
+//
+// LDS images (one stage = X image then Y image, every image a multiple of 1 KiB = one wave-wide DMA piece):
+//   k-contiguous operand ("row image"): [rows][128 B], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7):
+//     the 16 lanes a ds_read_b128 lane group serves (8 rows x chunk g, 8 rows x chunk g^1: MI355X_MICROARCH LDS table)
+//     then fall on 16 distinct 16-byte slots of the 256-byte bank row.
+//   k-strided operand ("col image"): 128-column sub-images [64 k][256 B], chunk ch of k-row r stored at
+//     ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) (cdna_hip_programming.md T10, image (b)): conflict free for the
+//     ds_read_b64_tr_b16 reads of the 16x16x32 operand (a half's two blocks are 8 k-rows apart).
+// An LDS-DMA piece lands lane-linear (base + 16 * lane), so the swizzle is applied to the per-lane SOURCE address and
+// again on the read -- never to the destination (rule 21 of the guide).
+// Bounds: rows past M / k-rows past K are cut off by the buffer descriptor's range check (returns zeros); column
+// overhang of a k-strided operand only reaches output columns the epilogue masks.  k-contiguous operands must keep
+// whole 128-byte stages inside their zero-padded rows (checked by the dispatcher).
+
+#ifndef BPM_DMA_ABLATE
+#define BPM_DMA_ABLATE 0      // lab builds only (tools/gemm_lab.py): 1 no MFMA, 2 no DMA in the loop, 4 no epilogue
+#endif
+constexpr int DK = 64;                     // k elements per stage
+constexpr int DROW = 128;                  // bytes of k per row-image row
+
+BPM_DEV int dma_row_off(int row, int c) { return row * DROW + ((c ^ ((row >> 1) & 7)) << 4); }
+BPM_DEV int dma_col_off(int krow, int ch) { return krow * 256 + ((ch ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4); }
+
+template <int N> BPM_DEV void dma_wait() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One operand side of the workgroup tile: ROWS rows of the output (a multiple of 128), NW waves in the workgroup.
+template <bool KCONTIG, int ROWS, int NW>
+struct DmaSide {
+    static constexpr int IMG_BYTES = ROWS * DROW;                 // both layouts: ROWS * 64 k * 2 B
+    static constexpr int PIECES = IMG_BYTES / 1024;
+    static constexpr int PER_WAVE = PIECES / NW;
+    static_assert(PIECES % NW == 0 && ROWS % 128 == 0, "pieces divide over the waves");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "piece -> swizzle mapping assumes 4, 8 or 16 waves");
+
+    // Wave w moves pieces w, w + NW, ...  The per-lane byte offset of its piece 0 -- the other pieces differ by a
+    // wave-uniform amount because the swizzle term repeats every 2 (row image) / 4 (col image) pieces.
+    static BPM_DEV int voffset(int ld, int row0, int wave, int lane) {
+        if (KCONTIG) {
+            const int row = 8 * wave + (lane >> 3), slot = lane & 7;
+            return (row0 + row) * ld * 2 + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        const int kr = 4 * wave + (lane >> 4), slot = lane & 15;      // piece = 4 k-rows of one 128-column sub-image
+        const int x = ((kr & 3) << 2) | ((kr >> 2) & 3);
+        return kr * ld * 2 + row0 * 2 + ((slot ^ x) << 4);
+    }
+    // wave-uniform byte offset of piece j relative to piece 0, and its LDS offset inside the image
+    static BPM_DEV int piece_goff(int ld, int j) {
+        if (KCONTIG) return j * 8 * NW * ld * 2;
+        return ((NW * j) >> 4) * 256 + 4 * ((NW * j) & 15) * ld * 2;     // sub-image (128 columns), then k-rows
+    }
+    static BPM_DEV int piece_lds(int wave, int j) {
+        if (KCONTIG) return (wave + j * NW) * 1024;
+        return ((NW * j) >> 4) * 16384 + (wave + ((NW * j) & 15)) * 1024;
+    }
+    static BPM_DEV int stage_step(int ld) { return KCONTIG ? DROW : DK * ld * 2; }
+
+    // DMA instruction j of this wave for one stage (soff: byte offset of the stage's k position).  A __device__
+    // function: with the LDS-DMA builtin directly in the kernel's lambda the host pass silently drops the kernel stub.
+    template <int J>
+    static BPM_DEV void issue_one(__amdgpu_buffer_rsrc_t rsrc, char* img, int voff, int soff, int ld, int wave) {
+        typedef __attribute__((address_space(3))) void* ldsp;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (ldsp)(img + piece_lds(wave, J)), 16, voff, soff + piece_goff(ld, J), 0, 0);
+    }
+
+    // MFMA operand of the 16 rows starting at r0 (multiple of 16), k-step ks (0 / 1) of the stage
+    static BPM_DEV bf16x8 frag(const char* img, int r0, int ks, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+        if (KCONTIG) return *(const bf16x8*)(img + dma_row_off(r0 + r, 4 * ks + g));
+        const int q = r >> 2, p = r & 3;
+        const char* sub = img + (r0 >> 7) * 16384;
+        const int ch = ((r0 & 127) >> 3) + (p >> 1);
+        const int k0 = 32 * ks + 8 * g + q;
+        typedef bf16x4 __attribute__((address_space(3))) * lds4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(sub + dma_col_off(k0, ch) + 8 * (p & 1)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(sub + dma_col_off(k0 + 4, ch) + 8 * (p & 1)));
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        return f;
+    }
+};
+
+// Part Q (0..3) of a stage's DMA instructions: the X pieces then the Y pieces of this wave, dealt over four quarters
+// of the stage's MFMA work so that the issue cost of a DMA (tens of cycles each, MI355X_MICROARCH cycle constants)
+// is spread between MFMA groups instead of heading the stage.
+template <typename SX, typename SY, int Q, int F = 0>
+BPM_DEV void dma_issue_part(__amdgpu_buffer_rsrc_t rsx, __amdgpu_buffer_rsrc_t rsy, char* bx, int vx, int vy, int sx, int sy,
+                            int ldx, int ldy, int wave) {
+    constexpr int LPS = SX::PER_WAVE + SY::PER_WAVE;
+    if constexpr (F < LPS) {
+        if constexpr ((F * 4) / LPS == Q) {
+            if constexpr (F < SX::PER_WAVE) SX::template issue_one<F>(rsx, bx, vx, sx, ldx, wave);
+            else SY::template issue_one<F - SX::PER_WAVE>(rsy, bx + SX::IMG_BYTES, vy, sy, ldy, wave);
+        }
+        dma_issue_part<SX, SY, Q, F + 1>(rsx, rsy, bx, vx, vy, sx, sy, ldx, ldy, wave);
+    }
+}
+
+// WMD x WND waves, each a (16 TMW) x 64 block of the (16 TMW WMD) x (64 WND) workgroup tile; NS LDS stages.
+template <bool XK, bool YK, int WMD, int WND, int TMW, int NS>
+__global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group grp) {
+    constexpr int NW = WMD * WND, BMD = 16 * TMW * WMD, BND = 64 * WND, WROWS = 16 * TMW;
+    typedef DmaSide<XK, BMD, NW> SX;
+    typedef DmaSide<YK, BND, NW> SY;
+    constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
+    constexpr int LPS = SX::PER_WAVE + SY::PER_WAVE;          // DMA instructions per wave and stage
+    static_assert(NS == 2 || NS == 3, "2 or 3 stages");
+    static_assert(TMW == 4 || TMW == 8, "wave tile 64 x 64 or 128 x 64");
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WND, wn = wave % WND;
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const Prob& P = pick_problem(grp, bid);
+    if (BPM_BASE_PRIO && XK && !(P.flags & BPM_GEMM_BACKGROUND)) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
+    const int m0 = (bid / P.tiles_n) * BMD, n0 = (bid % P.tiles_n) * BND;
+    const int nkt = (P.K + DK - 1) / DK;
+
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, (XK ? P.M : P.K) * P.ldx * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, (YK ? P.N : P.K) * P.ldy * 2, 0x00020000);
+    const int vx = SX::voffset(P.ldx, m0, wave, lane), vy = SY::voffset(P.ldy, n0, wave, lane);
+    const int stepx = SX::stage_step(P.ldx), stepy = SY::stage_step(P.ldy);
+    const int ldx = P.ldx, ldy = P.ldy;
+
+    auto part = [&](int kt, int buf, auto Q) {
+        dma_issue_part<SX, SY, decltype(Q)::value>(rsx, rsy, smem + buf * STAGE, vx, vy, kt * stepx, kt * stepy, ldx, ldy, wave);
+    };
+    auto stage = [&](int kt, int buf) {
+        part(kt, buf, std::integral_constant<int, 0>{}); part(kt, buf, std::integral_constant<int, 1>{});
+        part(kt, buf, std::integral_constant<int, 2>{}); part(kt, buf, std::integral_constant<int, 3>{});
+    };
+
+    f32x4 acc[4][TMW];                     // [n tile][m tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < TMW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] f32x4 xs[TMW];
+    [[maybe_unused]] bool do_xs = false;
+    if constexpr (!XK && !YK) {            // bias gradient beside a weight gradient: column sums of X (see the tiled kernel)
+        do_xs = P.colsum_x != nullptr && n0 == 0 && wn == 0;
+#pragma unroll
+        for (int b = 0; b < TMW; ++b) xs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nkt) stage(s, s);
+
+    int buf = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        // stage kt has landed once at most the younger stages' DMAs are outstanding (this wave's share), and for the
+        // other waves' shares once every wave has passed the barrier behind that wait
+        if (NS == 3 && kt + 1 < nkt) dma_wait<LPS>();
+        else dma_wait<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // our reads of the buffer about to be refilled are done
+        __builtin_amdgcn_s_barrier();
+        const bool more = kt + NS - 1 < nkt;                         // wave-uniform
+        const int nbuf = buf == 0 ? NS - 1 : buf - 1;                // the buffer stage kt-1 was read from
+        const char* ix = smem + buf * STAGE;
+        const char* iy = ix + SX::IMG_BYTES;
+        auto step = [&](auto KS) {
+            constexpr int ks = decltype(KS)::value;
+            bf16x8 fx[TMW], fy[4];
+#pragma unroll
+            for (int b = 0; b < TMW; ++b) fx[b] = SX::frag(ix, wm * WROWS + 16 * b, ks, lane);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fy[a] = SY::frag(iy, wn * 64 + 16 * a, ks, lane);
+            if constexpr (!XK && !YK) {
+                if (do_xs) {
+                    bf16x8 one;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) one[j] = (bf16_t)1.0f;
+#pragma unroll
+                    for (int b = 0; b < TMW; ++b) xs[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fx[b], xs[b], 0, 0, 0);
+                }
+            }
+            if (more && !(BPM_DMA_ABLATE & 2)) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks>{});
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < TMW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+            if (more && !(BPM_DMA_ABLATE & 2)) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks + 1>{});
+#pragma unroll
+            for (int a = 2; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < TMW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+        };
+        if (!(BPM_DMA_ABLATE & 1)) {
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+        } else if (more) stage(kt + NS - 1, nbuf);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    dma_wait<0>();                         // nothing of ours may still be writing LDS when the workgroup retires
+
+    const int r = lane & 15, g = lane >> 4;
+    const int mw = m0 + wm * WROWS;
+    if constexpr (!XK && !YK) {
+        if (do_xs && g == 0) {
+#pragma unroll
+            for (int b = 0; b < TMW; ++b) {
+                const int m = mw + 16 * b + r;
+                if (m < P.M) P.colsum_x[m] += xs[b][0];
+            }
+        }
+    }
+    if (BPM_DMA_ABLATE & 4) {              // lab: no epilogue traffic (keep the accumulators alive)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < TMW; ++b) asm volatile("" ::"v"(acc[a][b]));
+        return;
+    }
+    const bool fast = epi_fast_ok(P);
+    EpiRow rows[TMW];
+#pragma unroll
+    for (int b = 0; b < TMW; ++b) rows[b] = epi_row(P, mw + 16 * b + r);
+    // (explicitly unrolled: a rolled loop would index the accumulators dynamically and send them to scratch)
+    auto epi = [&](auto A) {
+        constexpr int a = decltype(A)::value;
+        epilogue_cols<bf16_t, TMW>(P, fast, true, mw, r, n0 + wn * 64 + 16 * a + 4 * g, acc[a], rows);
+    };
+    epi(std::integral_constant<int, 0>{}); epi(std::integral_constant<int, 1>{});
+    epi(std::integral_constant<int, 2>{}); epi(std::integral_constant<int, 3>{});
+}
