@@ -804,9 +804,11 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         fast = fast && bx < (1l << 31) - 65536 && by < (1l << 31) - 65536;
     }
     // LDS-DMA kernel (gemm_dma.h): bf16, no split-K, k-contiguous operands hold whole 128-byte stages inside their
-    // zero-padded rows.  Chosen (256 x 256 tiles) for the FFN-sized products -- measured on MI355X at hidden 768
-    // (tools/gemm_lab.py): fc1 265 -> 162 us, its data gradient 311 -> 270, FFN weight gradients 443 -> 408; the
-    // K = N = 768 products stay on the 128 x 64 kernel, whose 5 workgroups per CU overlap epilogues with main loops.
+    // zero-padded rows, epilogue 4-wide.  Measured on MI355X at hidden 768, six problems of 4096 rows per launch
+    // (tools/gemm_lab.py, us, register-staged 128 x 64 kernel -> 256 x 256 tile): q 84 -> 70, k/v 154 -> 108, out 80 ->
+    // 76, fc1 267 -> 172, fc2 245 -> 195, d(fc2) 314 -> 190, d(fc1) 185 -> 167, d(out) 82 -> 72, d(k/v) 135 -> 114,
+    // FFN weight gradients 445 -> 399 (8 waves of 128 x 64); the attention weight gradients (768 x 768 x 4096: nine
+    // 256 x 256 tiles per problem) stay on the 128 x 64 kernel (154 against 191).
     int dma = -1;
     if (dtype == BPM_BF16 && fast && g_force_dma != -2) {
         bool legal = true, big = true;
@@ -814,8 +816,12 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
             const bpm_gemm_problem& q = probs[i];
             const long kceil = ((long)q.K + DK - 1) / DK * DK;
             legal = q.splitk <= 1 && !(q.flags & BPM_GEMM_ATOMIC) && (!xk || kceil <= q.lda) && (!yk || kceil <= q.ldb);
+            // its epilogue is the 4-wide one only (epi_fast_ok, evaluated here on the host)
+            const uintptr_t al = (uintptr_t)q.bias_n | (uintptr_t)q.resid | (uintptr_t)q.C | (uintptr_t)q.gate;
+            legal = legal && (q.N & 3) == 0 && (al & 15) == 0 && ((q.ldr | q.ldc | q.ldg) & 3) == 0 && !q.bias_m &&
+                    !(q.resid && (q.flags & BPM_GEMM_ACCUM));
             const long tm = (q.M + 255) / 256, tn = (q.N + 255) / 256;
-            big = big && q.M >= 256 && q.N >= 256 && q.K >= 256 && (q.N >= 1024 || q.K >= 1024) &&
+            big = big && q.M >= 256 && q.N >= 256 && q.K >= 256 && (variant != BPM_GEMM_TN || tm * tn >= 24) &&
                   (double)q.M * q.N >= 0.8 * (double)(tm * 256) * (double)(tn * 256);
         }
         if (legal && g_force_dma >= 0) dma = g_force_dma;

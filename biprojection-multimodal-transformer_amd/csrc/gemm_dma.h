@@ -44,6 +44,105 @@ template <int N> BPM_DEV void dma_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---------------------------------------------------------------------------
+// Wide epilogue.  The MFMA leaves a lane with 4 consecutive n of 16 different rows per instruction, so a direct store
+// writes sixteen 64-byte (f32) / 32-byte (bf16) segments per wave instruction; at K = 768 that store pattern cost as
+// much as the whole main loop (lab: NT out 80 us with, 37 us without its epilogue).  After the k loop the stage
+// buffers are free: every wave passes its accumulators through a private 8 KB LDS block (32 rows x 64 f32, 16-byte
+// chunk c of row r stored at c ^ (r & 15): conflict-free both ways) and comes back with lane l holding columns
+// 4 (l & 15) .. + 3 of row l >> 4: each side-operand load and each store then covers four whole 256-byte (f32) /
+// 128-byte (bf16) row segments.  Same arithmetic per element as epilogue_fast (bit-identical results); only used for
+// problems that satisfy epi_fast_ok (the dispatcher checks it on the host).
+// ---------------------------------------------------------------------------
+BPM_DEV void flush_colsum_wide(const Prob& P, f32x4 cs, int nb, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = cs[q];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16 && nb + q < P.N) atomicAdd(P.colsum + nb + q, v);
+    }
+}
+
+// rows mrow + 4 * i (i < NI), columns nb .. nb + 3
+template <int NI>
+BPM_DEV void epilogue_wide(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NI], f32x4& csum) {
+    const bool colok = nb < P.N;
+    const uint32_t nbc = colok ? (uint32_t)nb : 0u;
+    const bool f32out = P.out_kind == BPM_OUT_F32;
+    const bool accum = f32out && (P.flags & BPM_GEMM_ACCUM);
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 addv[NI];
+    bf16x4 gt[NI];
+    if (P.bias_n) bias = *(const f32x4*)(P.bias_n + nbc);
+    if (P.gate) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) gt[i] = *(const bf16x4*)((const bf16_t*)P.gate + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldg + nbc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) gt[i] = bf16x4{};
+    }
+    if (P.resid) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) addv[i] = *(const f32x4*)(P.resid + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldr + nbc);
+    } else if (accum) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) addv[i] = *(const f32x4*)((const float*)P.C + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldc + nbc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) addv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const EpiRow e = epi_row(P, mrow + 4 * i);
+        const bool valid = e.ok && colok;
+        f32x4 x = acc[i];
+        if (valid) {
+            x += bias;
+            if (P.alpha != 1.f) x *= P.alpha;
+            if (P.flags & BPM_GEMM_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = fmaxf(x[q], 0.f);
+            }
+            if (P.gate) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = (float)gt[i][q] > 0.f ? x[q] * P.gate_scale : 0.f;
+            }
+            if (P.drop.thresh != 0) {
+                float d0, d1, d2, d3;
+                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb, d0, d1);
+                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb + 2u, d2, d3);
+                x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
+            }
+            csum += x;
+            x += addv[i];
+        }
+        if (f32out) {
+            if (valid) *(f32x4*)((float*)P.C + e.offc + nb) = x;
+        } else if (P.out_kind == BPM_OUT_CT) {
+            if (e.ok && nb < P.ldc) {                   // pad columns [N, ldc) receive zeros
+                if (!valid) x = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3];
+                *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o;
+            }
+        } else if (valid) {                             // head-major
+            uint32_t h = (uint32_t)nb / (uint32_t)P.hdh, c = (uint32_t)nb - h * (uint32_t)P.hdh;
+            const uint32_t hstride = (uint32_t)(P.hT * P.hdhp);
+            bf16_t* base = (bf16_t*)P.C + e.hrow;
+            if ((P.hdh & 3) == 0) {                     // the 4 columns stay inside one head
+                bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3];
+                *(bf16x4*)(base + h * hstride + c) = o;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    base[h * hstride + c] = (bf16_t)x[q];
+                    if (++c == (uint32_t)P.hdh) { c = 0; ++h; }
+                }
+            }
+        }
+    }
+}
+
 // One operand side of the workgroup tile: ROWS rows of the output (a multiple of 128), NW waves in the workgroup.
 template <bool KCONTIG, int ROWS, int NW>
 struct DmaSide {
@@ -229,6 +328,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
             }
         }
     }
+    static_assert(NS * STAGE >= NW * 8192, "one 8 KB transpose block per wave");
     if (BPM_DMA_ABLATE & 4) {              // lab: no epilogue traffic (keep the accumulators alive)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -236,15 +336,35 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
             for (int b = 0; b < TMW; ++b) asm volatile("" ::"v"(acc[a][b]));
         return;
     }
-    const bool fast = epi_fast_ok(P);
-    EpiRow rows[TMW];
+    // every wave is done reading the last stage before anyone overwrites LDS with accumulators
+    __builtin_amdgcn_s_barrier();
+    char* blk = smem + wave * 8192;        // NS * STAGE >= NW * 8 KB for every configuration
+    const int lr = lane >> 4, lc = lane & 15;
+    const int nbw = n0 + wn * 64 + 4 * lc;
+    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto pass = [&](auto PB) {             // rows 32 PB .. 32 PB + 31 of the wave tile
+        constexpr int pb = decltype(PB)::value;
+        if constexpr (pb < TMW / 2) {
 #pragma unroll
-    for (int b = 0; b < TMW; ++b) rows[b] = epi_row(P, mw + 16 * b + r);
-    // (explicitly unrolled: a rolled loop would index the accumulators dynamically and send them to scratch)
-    auto epi = [&](auto A) {
-        constexpr int a = decltype(A)::value;
-        epilogue_cols<bf16_t, TMW>(P, fast, true, mw, r, n0 + wn * 64 + 16 * a + 4 * g, acc[a], rows);
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int row = 16 * bb + r;
+                    *(f32x4*)(blk + row * 256 + (((4 * a + g) ^ (row & 15)) << 4)) = acc[a][2 * pb + bb];
+                }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {           // 16 rows at a time: 4 row steps per lane in flight
+                f32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 16 * hf + 4 * i + lr;
+                    v[i] = *(const f32x4*)(blk + row * 256 + ((lc ^ (row & 15)) << 4));
+                }
+                epilogue_wide<4>(P, mw + 32 * pb + 16 * hf + lr, nbw, v, cs);
+            }
+        }
     };
-    epi(std::integral_constant<int, 0>{}); epi(std::integral_constant<int, 1>{});
-    epi(std::integral_constant<int, 2>{}); epi(std::integral_constant<int, 3>{});
+    pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{});
+    pass(std::integral_constant<int, 2>{}); pass(std::integral_constant<int, 3>{});
+    if (P.colsum) flush_colsum_wide(P, cs, nbw, lane);
 }

@@ -6,13 +6,25 @@ which re-replicates the module and reduces every gradient onto GPU 0 each
 step.  Here every rank holds a replica; the batch axis is sharded; the only
 exchange per optimizer step is a sum of gradients followed by 1/world_size
 (equal to the reference's mean loss over the global batch for equal shards).
+With gradient accumulation (train.py:390-398) only the last micro-step
+exchanges: set `sync.active = False` on the others.
 
 The trunk's gradients live in ONE flat fp32 buffer laid out in reverse
-execution order (Fusion-GMU, level-2 encoders, level-1 encoders, projections),
-so each section can be all-reduced, as a few large messages, on a side stream
-as soon as backward has finished it, overlapping with the rest of backward.
-The [B,d]-sized tail's parameters (a few hundred KB) are reduced as one
-flattened message at the end.
+execution order (Fusion-GMU, level-2 encoders, level-1 encoders, projections)
+at LAYER granularity, so each slice is all-reduced, as a few large messages, on
+a communication stream as soon as backward has finished it, overlapping with
+the rest of backward.  The [B,d]-sized tail's parameters (a few hundred KB) are
+reduced as one flattened message at the end.
+
+* 1/world is NOT a separate pass over the gradient buffer when a FusedAdam is
+  attached (`GradSync(model, optimizer=opt)`): finish() leaves the SUM in the
+  flat buffer and hands 1/world to the optimizer, whose kernel multiplies the
+  gradient as it reads it (`bpm_adam_step(grad_scale)`).  Without an optimizer
+  the buffer is scaled in place so that `.grad` holds the mean.
+* `compress="bf16"` (opt-in) exchanges bf16 copies of the slices: half the
+  bytes on the xGMI ring (hidden 768, 4-modal: 1.85 GB of fp32 gradients are
+  ~21 ms of ring all-reduce) for one rounding of each
+  rank's summand; the sum is accumulated by RCCL in bf16.
 """
 from __future__ import annotations
 
@@ -23,13 +35,20 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, bucket_bytes: int = 128 << 20, process_group=None):
+    def __init__(self, model, bucket_bytes: int = 128 << 20, process_group=None, optimizer=None, compress: str = "none"):
+        if compress not in ("none", "bf16"):
+            raise ValueError("compress must be 'none' or 'bf16'")
         self.model, self.pg = model, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket = bucket_bytes // 4
+        self.optimizer = optimizer
+        self.compress = compress
         self.comm: Optional[torch.cuda.Stream] = None
         self.handles: List = []
+        self._half: List = []        # (bf16 staging buffer, fp32 slice) pairs of the step in flight
         self.active = True           # set False on non-final gradient-accumulation micro-steps
+        self._exposed: List = []     # (event before waiting for the exchange, event after) per step
+        self._bytes = 0
         model._grad_ready_hook = self._on_ready
 
     def _on_ready(self, flat: torch.Tensor, lo: int, hi: int, events=None) -> None:
@@ -47,27 +66,64 @@ class GradSync:
         with torch.cuda.stream(self.comm):
             for a in range(lo, hi, self.bucket):
                 b = min(hi, a + self.bucket)
-                self.handles.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.compress == "bf16":
+                    half = flat[a:b].to(torch.bfloat16)
+                    self._half.append((half, flat[a:b]))
+                    self.handles.append(dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    self._bytes += 2 * (b - a)
+                else:
+                    self.handles.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    self._bytes += 4 * (b - a)
 
     def finish(self) -> None:
-        """After loss.backward(): reduce the tail, wait for everything, scale by 1/world."""
+        """After loss.backward(): reduce the tail, wait for everything, apply (or hand on) 1/world."""
         if self.world == 1 or not self.active:
             return
         st = self.model._store
         tail = [p.grad for n, p in self.model.named_parameters() if p.grad is not None and n not in st.params]
-        for h in self.handles:
-            h.wait()
-        self.handles.clear()
+        main = torch.cuda.current_stream()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record(main)
         if self.comm is not None:
-            torch.cuda.current_stream().wait_stream(self.comm)
+            with torch.cuda.stream(self.comm):          # the communication stream waits for RCCL, the main stream for it
+                for h in self.handles:
+                    h.wait()
+                for half, dst in self._half:
+                    dst.copy_(half)
+            self._half.clear()
+            main.wait_stream(self.comm)
+        self.handles.clear()
         inv = 1.0 / self.world
         if tail:
             flat = torch._utils._flatten_dense_tensors(tail)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
-            flat.mul_(inv)
+            if self.optimizer is None:
+                flat.mul_(inv)
             for g, f in zip(tail, torch._utils._unflatten_dense_tensors(flat, tail)):
                 g.copy_(f)
-        st.gflat.mul_(inv)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(main)
+        self._exposed.append((e0, e1))
+        if self.optimizer is not None:
+            self.optimizer.pending_grad_scale = inv      # consumed (and reset) by the next FusedAdam.step()
+        else:
+            st.gflat.mul_(inv)
+
+    # -- measurement aid for bench.py ---------------------------------------------
+    def reset_stats(self) -> None:
+        self._exposed.clear()
+        self._bytes = 0
+
+    def stats(self) -> dict:
+        """Exposed exchange time per step: how long the main stream sat between the end of backward and the end of
+        the last all-reduce (the part that did not overlap backward)."""
+        if not self._exposed:
+            return {"world": self.world, "steps": 0}
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        n = len(ms)
+        return {"world": self.world, "steps": n, "exposed_ms_per_step": round(sum(ms) / n, 3),
+                "bytes_per_step": self._bytes // n, "compress": self.compress}
 
 
 def reduce_gradients_cpu(params, world: int, group=None) -> None:

@@ -133,17 +133,27 @@ class ParamStore:
         return self._gviews[name].data_ptr() + 4 * elem_off
 
     def still_flat(self) -> bool:
-        """False after model.to()/.cuda()/.float() replaced the parameter storages."""
-        n0, n1 = self.names[0], self.names[-1]
-        return (self.params[n0].data_ptr() == self._master_ptr + 4 * self.off[n0]
-                and self.params[n1].data_ptr() == self._master_ptr + 4 * self.off[n1])
+        """False after anything re-pointed a parameter's storage (model.to()/.cuda()/.float(), `p.data = ...`, a
+        child module that built a ParamStore of its own): the launch tables cache raw pointers into `master`, so
+        every parameter is checked (~1700 integer comparisons)."""
+        base = self._master_ptr
+        return all(p.data_ptr() == base + 4 * self.off[n] for n, p in self.params.items())
+
+    def _fresh(self) -> bool:
+        """Gradients are unset (backward starts from zero) iff the first TRAINABLE parameter has no .grad: a frozen
+        first parameter never gets one and must not make every micro-step look fresh."""
+        for n in self.names:
+            p = self.params[n]
+            if p.requires_grad:
+                return p.grad is None
+        return True
 
     def prezero(self) -> None:
         """Called at the start of a training forward: if the gradients are unset now (the usual zero_grad /
         `p.grad = None` step), clear the flat gradient buffer on the side stream while the forward pass runs, instead
         of on the critical path when backward starts."""
         self._prezero_ev = None
-        if self.params[self.names[0]].grad is None and _SIDE:
+        if self._fresh() and _SIDE:
             main = torch.cuda.current_stream()
             side = _side_stream(main.device)
             side.wait_stream(main)                      # the previous step's consumers of gflat (optimizer, all-reduce)
@@ -155,7 +165,7 @@ class ParamStore:
     def begin_backward(self) -> None:
         """Gradients accumulate into gflat like autograd accumulates into .grad:
         a parameter whose .grad is None starts from zero."""
-        fresh = self.params[self.names[0]].grad is None
+        fresh = self._fresh()
         ev = getattr(self, "_prezero_ev", None)
         self._prezero_ev = None
         if fresh and ev is not None:

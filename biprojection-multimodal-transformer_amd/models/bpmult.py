@@ -502,7 +502,9 @@ class _BPMulTBase(nn.Module):
         self.out_layer = nn.Linear(d, args.n_classes)
         self._store: Optional[ParamStore] = None
         self._trunks: Dict[int, _Trunk] = {}
-        self._step = 0
+        # host-side step counter of the dropout stream; FusedAdam.state_dict() carries it (the model's state_dict keys
+        # stay exactly the reference's), so a resumed run continues the mask sequence
+        self.dropout_step = 0
 
     def _init_time_maps(self):
         L, A, V = self.num_vectors_l, self.num_vectors_a, self.num_vectors_v
@@ -568,11 +570,17 @@ class _BPMulTBase(nn.Module):
             self._anchor = torch.zeros(1, device=st.device, requires_grad=True)
         return self._store
 
+    MAX_TRUNKS = 2          # activation buffer sets kept (one per batch size, multi-GB each): most recently used
+
     def _trunk_for(self, B: int) -> _Trunk:
         self._ensure_store()
-        if B not in self._trunks:
-            self._trunks[B] = _Trunk(self, B)
-        return self._trunks[B]
+        t = self._trunks.pop(B, None)
+        if t is None:
+            while len(self._trunks) >= self.MAX_TRUNKS:
+                self._trunks.pop(next(iter(self._trunks)))         # least recently used
+            t = _Trunk(self, B)
+        self._trunks[B] = t                                         # (re)insert as most recent
+        return t
 
     def set_prune_unused_rows(self, flag: bool) -> None:
         """Switch the level-2 / GMU schedule between dense (reference) and rows {0, N-1} only (same logits and
@@ -581,8 +589,13 @@ class _BPMulTBase(nn.Module):
         self._trunks = {}
 
     def _next_seed(self) -> int:
-        self._step += 1
-        return (torch.initial_seed() * 1000003 + self._step) & 0xFFFFFFFFFFFFFFFF
+        """Dropout seed of the next forward pass: (process seed, data-parallel rank, step).  Ranks that seed alike
+        must still draw independent masks on their shards, as the reference's DataParallel replicas do; the step
+        counter is saved with the optimizer state (FusedAdam.state_dict) so a resumed run does not
+        replay the mask sequence from step 1."""
+        self.dropout_step += 1
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        return (torch.initial_seed() * 1000003 + rank * 0x9E3779B97F4A7C15 + int(self.dropout_step)) & 0xFFFFFFFFFFFFFFFF
 
     def _fuse_and_head(self, outs, extra):
         """[B,d]-sized tail: level 1->3 residual + first/last token (mmtr.py:806-808), final GMU, residual head."""

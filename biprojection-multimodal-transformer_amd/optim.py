@@ -1,10 +1,14 @@
 """Fused flat Adam for the BPMulT trunk.
 
-The reference trains with `torch.optim.Adam(model.parameters(), lr=...)` (train.py:123-125) and steps it after the
-backward pass (train.py:396-398).  Here every trunk parameter is a view into one flat fp32 master buffer and its
-gradient a view into one flat gradient buffer (engine.ParamStore), so the optimizer step for ~all of the model is ONE
-streaming kernel (`bpm_adam_step`) instead of a foreach loop over ~1700 tensors; the few parameters outside the trunk
-(final GMU, head, front-ends) go through an ordinary torch.optim.Adam with the same hyper-parameters.
+The reference trains with `torch.optim.Adam(model.parameters(), lr=...)` (train.py:123-125), wraps it in
+`ReduceLROnPlateau` (train.py:128-136), steps it after the backward pass (train.py:396-398) and stores
+`optimizer.state_dict()` in its checkpoints (train.py:372-379).  Here every trunk parameter is a view into one flat fp32
+master buffer and its gradient a view into one flat gradient buffer (engine.ParamStore), so the optimizer step for ~all
+of the model is ONE streaming kernel (`bpm_adam_step`) instead of a foreach loop over ~1700 tensors; the few parameters
+outside the trunk (final GMU, head, front-ends) go through an ordinary torch.optim.Adam with the same hyper-parameters.
+
+`FusedAdam` IS a `torch.optim.Optimizer` (one param group holding every model parameter), so LR schedulers and the
+reference's checkpoint code accept it; `param_groups[0]["lr"]` is read at every step.
 """
 from __future__ import annotations
 
@@ -15,23 +19,31 @@ import torch
 from . import _lib
 
 
-class FusedAdam:
+class FusedAdam(torch.optim.Optimizer):
     """Drop-in for `torch.optim.Adam(model.parameters(), lr, betas, eps, weight_decay)` on a `bpmult_amd` model.
 
     Differences from torch.optim.Adam, all deliberate: trunk parameters that never receive a gradient keep a zero
     gradient instead of `None` (their update is exactly zero unless weight_decay > 0); `zero_grad()` clears the flat
-    gradient buffer in place (fused into the step when `fused_zero_grad=True`)."""
+    gradient buffer in place (fused into the step when `fused_zero_grad=True`); the moments are two flat buffers
+    (`state_dict()["flat"]`), not per-parameter tensors."""
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  fused_zero_grad: bool = False):
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.model = model
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.fused_zero_grad = fused_zero_grad
         self.step_count = 0
+        self.pending_grad_scale: Optional[float] = None      # set by distributed.GradSync.finish(): 1 / world_size
         self._m: Optional[torch.Tensor] = None
         self._v: Optional[torch.Tensor] = None
         self._store_id = None
         self._tail_opt = None
+
+    # hyper-parameters live in the param group (what schedulers write)
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
 
     # -- plumbing ---------------------------------------------------------------
     def _store(self):
@@ -40,14 +52,11 @@ class FusedAdam:
             self._m = torch.zeros_like(st.master)
             self._v = torch.zeros_like(st.master)
             self._store_id = id(st)
+            g = self.param_groups[0]
             tail = [p for n, p in self.model.named_parameters() if n not in st.params and p.requires_grad]
-            self._tail_opt = torch.optim.Adam(tail, lr=self.lr, betas=self.betas, eps=self.eps,
-                                              weight_decay=self.weight_decay) if tail else None
+            self._tail_opt = torch.optim.Adam(tail, lr=g["lr"], betas=g["betas"], eps=g["eps"],
+                                              weight_decay=g["weight_decay"]) if tail else None
         return st
-
-    @property
-    def param_groups(self):                                # ReduceLROnPlateau & friends read / write lr here
-        return [self.__dict__]
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         st = self._store()
@@ -56,36 +65,50 @@ class FusedAdam:
             self._tail_opt.zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0) -> None:
+    def step(self, closure=None, grad_scale: Optional[float] = None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         st = self._store()
+        g = self.param_groups[0]
+        if grad_scale is None:
+            grad_scale = self.pending_grad_scale if self.pending_grad_scale is not None else 1.0
+        self.pending_grad_scale = None
         self.step_count += 1
         n = st.master.numel()
-        pad = (-n) % 4
-        if pad:
+        if n % 4:
             raise RuntimeError("flat parameter buffer is not a multiple of 4 elements")
         _lib.check(_lib.lib().bpm_adam_step(st.master.data_ptr(), st.gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n,
-                                            self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                            g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                             self.step_count, grad_scale, int(self.fused_zero_grad),
                                             torch.cuda.current_stream().cuda_stream), "bpm_adam_step")
         if self._tail_opt is not None:
-            for g in self._tail_opt.param_groups:
-                g["lr"] = self.lr
+            for tg in self._tail_opt.param_groups:
+                tg["lr"], tg["betas"], tg["eps"], tg["weight_decay"] = g["lr"], g["betas"], g["eps"], g["weight_decay"]
             if grad_scale != 1.0:
                 for p in self._tail_opt.param_groups[0]["params"]:
                     if p.grad is not None:
                         p.grad.mul_(grad_scale)
             self._tail_opt.step()
+        return loss
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self._m, "exp_avg_sq": self._v,
+        self._store()                                      # the moments exist (zeros) even before the first step
+        g = self.param_groups[0]
+        return {"step": self.step_count, "flat": {"exp_avg": self._m, "exp_avg_sq": self._v},
                 "tail": self._tail_opt.state_dict() if self._tail_opt is not None else None,
-                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+                "dropout_step": int(getattr(self.model, "dropout_step", 0)),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"}]}
 
     def load_state_dict(self, sd) -> None:
         self._store()
         self.step_count = sd["step"]
-        self._m.copy_(sd["exp_avg"])
-        self._v.copy_(sd["exp_avg_sq"])
+        self._m.copy_(sd["flat"]["exp_avg"])
+        self._v.copy_(sd["flat"]["exp_avg_sq"])
         if self._tail_opt is not None and sd.get("tail") is not None:
             self._tail_opt.load_state_dict(sd["tail"])
-        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        if hasattr(self.model, "dropout_step"):
+            self.model.dropout_step = int(sd.get("dropout_step", 0))
+        for k, v in sd["param_groups"][0].items():
+            self.param_groups[0][k] = tuple(v) if k == "betas" else v

@@ -118,3 +118,24 @@ def test_model_surface_matches_reference_registry():
     # attention dropout is keyed by the key/value source modality (reference get_network tags)
     assert m.trans_a_with_l.attn_dropout == 0.1 and m.trans_l_with_a.attn_dropout == 0.0 and m.trans_l_with_v2a.attn_dropout == 0.0
     assert m.trans_v_with_a2l.attn_dropout == 0.1
+
+
+def test_fused_adam_is_a_torch_optimizer_for_the_reference_loop():
+    """The reference wraps its optimizer in ReduceLROnPlateau (train.py:128-136) and checkpoints optimizer.state_dict()
+    (train.py:372-379): FusedAdam must be accepted by both (it is a torch.optim.Optimizer whose param group carries lr)."""
+    import torch
+    from types import SimpleNamespace
+    from bpmult_amd.models import get_model
+    from bpmult_amd.optim import FusedAdam
+    a = SimpleNamespace(model="mmtrvat", orig_d_l=32, orig_d_v=35, orig_d_a=74, orig_d_p=64, hidden_sz=24, vonly=True, lonly=True,
+                        aonly=True, num_heads=4, layers=1, attn_dropout=0., attn_dropout_v=0., attn_dropout_a=0., relu_dropout=0.,
+                        res_dropout=0., out_dropout=0., embed_dropout=0., attn_mask=True, hybrid=False, n_classes=6,
+                        bert_model="unused", text_features=True)
+    model = get_model(a)
+    opt = FusedAdam(model, lr=1e-3)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "max", patience=0, factor=0.5)
+    sched.step(1.0)
+    sched.step(0.5)             # no improvement -> lr halves
+    assert abs(opt.param_groups[0]["lr"] - 5e-4) < 1e-12 and abs(opt.lr - 5e-4) < 1e-12
+    assert len(opt.param_groups) == 1 and len(opt.param_groups[0]["params"]) == len([p for p in model.parameters() if p.requires_grad])

@@ -27,10 +27,24 @@ def test_metric_is_baseline_json_verbatim():
 
 def test_traffic_file_covers_the_profiled_kernel_families():
     b = _bench()
-    for kind in b.KIND_TO_FAMILY:
-        t = b.hbm_traffic(kind)
-        assert t is None or t > 0
-    assert b.hbm_traffic("gemm_tn") and b.hbm_traffic("gemm_tn") > 5e7      # committed PMC measurement present
+    for cfg in ("h768", "cfg1"):
+        for kind in b.KIND_TO_FAMILY:
+            t = b.hbm_traffic(cfg, kind)
+            assert t is None or t > 0
+    assert b.hbm_traffic("cfg1", "gemm_tn") and b.hbm_traffic("cfg1", "gemm_tn") > 5e7      # committed PMC measurement present
+    if os.path.exists(os.path.join(ROOT, "profiles", b.TRAFFIC_FILES["h768"])):
+        assert b.hbm_traffic("h768", "gemm_tn") > 5e7 and b.hbm_traffic("h768", "gemm_nt") > 5e7
+
+
+def test_default_workload_is_the_metric_configuration():
+    """BASELINE.json's metric is quoted on hidden 768, 3-modal unaligned: that is what `value` must describe."""
+    b = _bench()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert "default: h768" in out.stdout.replace("(default", "default").replace("'", "") or "h768" in out.stdout
+    c = b.CONFIGS["h768"]
+    assert c["hidden_sz"] == 768 and c["model"] == "mmtrvat" and (c["L"], c["V"], c["A"]) == (20, 500, 400)
+    import inspect
+    assert 'default="h768"' in inspect.getsource(b.main)
 
 
 def test_workloads_and_cli():

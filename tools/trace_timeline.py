@@ -11,15 +11,16 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(gemm_tiled_kernel|gemm_astat_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|ln_fwd_kernel|"
+    m = re.search(r"(gemm_tiled_kernel|gemm_dma_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|ln_fwd_kernel|"
                   r"ln_bwd_kernel|ln_fwd_vec_kernel|ln_bwd_vec_kernel|rows_cast_kernel|colsum_kernel|fold_bias_kernel|"
                   r"unfold_grads_kernel|embed_pos_fwd_kernel|embed_pos_bwd_kernel|pack_rows_\w+_kernel|gmu2_\w+_kernel|"
                   r"pack_weights_kernel)", name)
     if m:
         k = m.group(1)
-        if k == "gemm_tiled_kernel":      # needs mangled names (rocprofv3 -M): the demangler garbles __bf16 templates
+        if k in ("gemm_tiled_kernel", "gemm_dma_kernel"):      # needs mangled names (rocprofv3 -M): the demangler garbles __bf16 templates
             m2 = re.search(r"gemm_tiled_kernelI(?:DF16b|f)Lb([01])ELb([01])E", name) or \
-                re.search(r"gemm_tiled_kernel<[^,]+, (true|false), (true|false)", name)
+                re.search(r"gemm_tiled_kernel<[^,]+, (true|false), (true|false)", name) or \
+                re.search(r"gemm_dma_kernelILb([01])ELb([01])E", name) or re.search(r"gemm_dma_kernel<(true|false), (true|false)", name)
             if m2:
                 xk, yk = (g in ("1", "true") for g in m2.groups())
                 k += "<NT>" if (xk and yk) else "<NN>" if xk else "<TN>"
