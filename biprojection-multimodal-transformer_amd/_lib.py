@@ -144,6 +144,8 @@ SIGNATURES = {
     "bpm_embed_pos_bwd": [C.POINTER(EmbedProblem), _I, _I, _F, _U64, _P],
     "bpm_ln_fwd": [_I, C.POINTER(LnProblem), _I, _I, _F, _P],
     "bpm_ln_bwd": [_I, C.POINTER(LnProblem), _I, _I, _U64, _P],
+    "bpm_ln_bwd_ws": [_I, C.POINTER(LnProblem), _I, _I, _U64, _P, C.c_size_t, _P],
+    "bpm_ln_bwd_ws_bytes": [_I, _I],
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
@@ -173,7 +175,7 @@ def lib() -> C.CDLL:
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the symbol is missing
             fn.argtypes = args
-            fn.restype = C.c_char_p if name == "bpm_error_string" else C.c_int
+            fn.restype = C.c_char_p if name == "bpm_error_string" else C.c_size_t if name == "bpm_ln_bwd_ws_bytes" else C.c_int
         if L.bpm_version() != 1:
             raise HipLibraryError("libbpmult_hip.so ABI version mismatch")
         _lib = L

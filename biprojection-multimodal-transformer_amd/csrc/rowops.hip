@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const Grp<LnP> grp, int 
 }
 
 template <typename CT, int NV>
-__global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int d) {
+__global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int d, float* __restrict__ ws) {
     if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     __shared__ float red[3][NT / 64][NV * 256];
     unsigned bid = blockIdx.x, nblk;
@@ -496,12 +496,47 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int 
         *(f32x4*)(&red[2][wv][4 * (lane + 64 * e)]) = ac[e];
     }
     __syncthreads();
+    // Per-block column sums.  With a workspace every block stores its three rows and ln_bwd_reduce_kernel adds them up
+    // (one owner per column, fixed order: bitwise reproducible).  Without one they go out as float atomics -- up to 128
+    // blocks per problem adding into the same three 3 KB rows, which runs an order of magnitude below the atomic rate
+    // (MI355X_MICROARCH, global float atomics, contention row) and was ~half of this kernel's time at hidden 768.
+    float* mine = ws ? ws + (size_t)blockIdx.x * 3 * d : nullptr;
     for (int c = threadIdx.x; c < d; c += NT) {
         float sg = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; sc += red[2][w][c]; }
+        if (mine) { mine[c] = sg; mine[d + c] = sb; mine[2 * d + c] = sc; continue; }
         if (want_g) { atomicAdd(P.dgamma + c, sg); atomicAdd(P.dbeta + c, sb); }
         if (want_c) atomicAdd(P.csum + c, sc);
+    }
+}
+
+// second stage of the LayerNorm backward's parameter / bias gradients: column c of problem p = sum over that
+// problem's blocks, added (+=) into dgamma / dbeta / the cast column sums by a single owner.  Block = 64 columns x 4
+// row groups (each sums a quarter of the partial rows, 8 loads in flight), combined through LDS.
+__global__ __launch_bounds__(NT) void ln_bwd_reduce_kernel(const Grp<LnP> grp, int d, const float* __restrict__ ws, int cblk) {
+    __shared__ float part[3][4][64];
+    const int pi = blockIdx.x / cblk, col = threadIdx.x & 63, grp4 = threadIdx.x >> 6;
+    const int c = (blockIdx.x % cblk) * 64 + col;
+    const LnP& P = grp.p[pi];
+    const bool want_g = P.dgamma != nullptr, want_c = P.cast != nullptr && P.csum != nullptr;
+    if (!want_g && !want_c) return;                   // uniform per block
+    float sg = 0.f, sb = 0.f, sc = 0.f;
+    if (c < d) {
+#pragma unroll 8
+        for (unsigned b = grp.blk0[pi] + grp4; b < grp.blk0[pi + 1]; b += 4) {
+            const float* r = ws + (size_t)b * 3 * d;
+            sg += r[c]; sb += r[d + c]; sc += r[2 * d + c];
+        }
+    }
+    part[0][grp4][col] = sg; part[1][grp4][col] = sb; part[2][grp4][col] = sc;
+    __syncthreads();
+    if (grp4 == 0 && c < d) {
+        sg = (part[0][0][col] + part[0][1][col]) + (part[0][2][col] + part[0][3][col]);
+        sb = (part[1][0][col] + part[1][1][col]) + (part[1][2][col] + part[1][3][col]);
+        sc = (part[2][0][col] + part[2][1][col]) + (part[2][2][col] + part[2][3][col]);
+        if (want_g) { P.dgamma[c] += sg; P.dbeta[c] += sb; }
+        if (want_c) P.csum[c] += sc;
     }
 }
 
@@ -844,7 +879,11 @@ extern "C" int bpm_ln_fwd(int dtype, const bpm_ln_problem* q, int n, int d, floa
     return BPM_ERR_ARG;
 }
 
-extern "C" int bpm_ln_bwd(int dtype, const bpm_ln_problem* q, int n, int d, uint64_t seed, void* stream) {
+extern "C" size_t bpm_ln_bwd_ws_bytes(int n, int d) {
+    return (size_t)(n > 0 ? n : 0) * 128 * 3 * (size_t)(d > 0 ? d : 0) * sizeof(float);
+}
+
+extern "C" int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* q, int n, int d, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
     if (dtype != BPM_F32 && dtype != BPM_BF16) return BPM_ERR_ARG;
     Grp<LnP> g;
     int span;
@@ -852,15 +891,29 @@ extern "C" int bpm_ln_bwd(int dtype, const bpm_ln_problem* q, int n, int d, uint
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (ln_vec_ok(q, n, d, true, dtype == BPM_BF16 ? 2 : 4)) {
-        // two rows per wave and iteration: half the blocks of the scalar kernel (and half its atomics)
+        // two rows per wave and iteration: half the blocks of the scalar kernel
         for (int i = 0; i < n; ++i) g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)q[i].R, 8, 128);
         int maxw = d;
-        for (int i = 0; i < n; ++i) if (q[i].cast && q[i].ldc > maxw) maxw = q[i].ldc;
+        bool sums = false;
+        for (int i = 0; i < n; ++i) {
+            if (q[i].cast && q[i].ldc > maxw) maxw = q[i].ldc;
+            sums = sums || q[i].dgamma || (q[i].cast && q[i].cast_colsum);
+        }
+        float* w = nullptr;
+        if (ws && sums) {
+            if (((uintptr_t)ws & 15) || ws_bytes < (size_t)g.blk0[n] * 3 * d * sizeof(float)) return BPM_ERR_ARG;
+            w = (float*)ws;
+        }
 #define BPM_LN_BWDV(NV)                                                                                        \
         if (maxw <= 256 * NV) {                                                                                \
-            if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d); \
-            else hipLaunchKernelGGL((ln_bwd_vec_kernel<float, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d);                   \
+            if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, w); \
+            else hipLaunchKernelGGL((ln_bwd_vec_kernel<float, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, w);                   \
             BPM_CHECK_LAUNCH();                                                                                \
+            if (w) {                                                                                           \
+                const int cblk = (d + 63) / 64;                                                                \
+                hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(n * cblk), dim3(NT), 0, s, g, d, w, cblk);       \
+                BPM_CHECK_LAUNCH();                                                                            \
+            }                                                                                                  \
             return 0;                                                                                          \
         }
         BPM_LN_BWDV(1) BPM_LN_BWDV(2) BPM_LN_BWDV(3) BPM_LN_BWDV(4)
@@ -876,6 +929,10 @@ extern "C" int bpm_ln_bwd(int dtype, const bpm_ln_problem* q, int n, int d, uint
     BPM_LN_BWD(1) BPM_LN_BWD(2) BPM_LN_BWD(5) BPM_LN_BWD(8) BPM_LN_BWD(12) BPM_LN_BWD(16) BPM_LN_BWD(24) BPM_LN_BWD(32)
 #undef BPM_LN_BWD
     return BPM_ERR_ARG;
+}
+
+extern "C" int bpm_ln_bwd(int dtype, const bpm_ln_problem* q, int n, int d, uint64_t seed, void* stream) {
+    return bpm_ln_bwd_ws(dtype, q, n, d, seed, nullptr, 0, stream);
 }
 
 extern "C" int bpm_rows_cast(int dtype, const bpm_cast_problem* q, int n, uint64_t seed, void* stream) {

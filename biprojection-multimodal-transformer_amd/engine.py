@@ -247,7 +247,21 @@ class ParamStore:
     def sptr(self, key: str, elem_off: int = 0) -> int:
         return self.shadow_flat.data_ptr() + self.shadow_flat.element_size() * (self._shadow_off[key] + elem_off)
 
-    def refresh_shadows(self) -> None:
+    def mark_dirty(self) -> None:
+        """The master weights were changed through raw pointers (bpm_adam_step): the CT shadows are stale."""
+        self._dirty = True
+
+    def _versions(self) -> int:
+        return sum(p._version for p in self.params.values())
+
+    def refresh_shadows(self, force: bool = False) -> None:
+        """Re-derive the CT weight shadows and folded biases from the fp32 masters -- only when the masters changed
+        since the last refresh (an optimizer step, load_state_dict, any in-place edit: torch's per-tensor version
+        counters, or mark_dirty() for raw-pointer writers).  In a training loop that is once per optimizer step."""
+        sig = self._versions()
+        if not force and not getattr(self, "_dirty", True) and sig == getattr(self, "_shadow_sig", None):
+            return
+        self._dirty, self._shadow_sig = False, sig
         if self._table is not None:
             ops.pack_weights(self.dtype, self._table, self._ndesc, self._nblk)
         if self._fold_table is not None:
@@ -287,7 +301,10 @@ class GroupCfg:
 
 SIDE, JOIN, MARK, WAIT, SIDE2 = "side", "join", "mark", "wait", "side2"
 _SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
-_DKV_SIDE = os.environ.get("BPMULT_DKV_SIDE", "0")       # "1": dK/dV pass on the side stream, "2": on a third stream
+# dK/dV attention pass: "0" main stream, "1" side stream, "2" a third stream, "auto": side stream at hidden >= 512.
+# dK / dV feed only side-stream work (weight gradients, key/value dgrad).  At hidden 300 the side stream is the longer
+# one and moving the pass there costs 1 ms/step; at hidden 768 the main stream is (41 ms against 23) and it saves ~4.
+_DKV_SIDE_ENV = os.environ.get("BPMULT_DKV_SIDE", "auto")
 _side_streams: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
@@ -405,6 +422,7 @@ class EncoderGroupPlan:
                 blk += (2 * d + 15) // 16
                 ud.append(u)
             self._unfold.append((ops.device_table(ud), len(ud), blk))
+        self._dkv_side = _DKV_SIDE_ENV if _DKV_SIDE_ENV != "auto" else ("1" if d >= 512 else "0")
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
         self._bwd = {True: self._build_bwd(True), False: self._build_bwd(False)}
 
@@ -723,10 +741,9 @@ class EncoderGroupPlan:
                       (ops.ln_bwd, A(LnProblem, lnf), d),
                       self._gemm(GEMM_NN, dg_out),
                       (ops.attn_bwd_dq, self.dtype, A(AttnProblem, att)),
-                      # dK / dV feed only side work, but running their pass beside the main chain measured SLOWER
-                      # (17.7 -> 18.7 ms/step: the side stream becomes the longer one); opt-in for experiments
-                      ((SIDE if _DKV_SIDE == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
-                       if _DKV_SIDE in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
+                      # dK / dV feed only side work: beside the main chain where the side stream has slack (see _DKV_SIDE_ENV)
+                      ((SIDE if self._dkv_side == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
+                       if self._dkv_side in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
                       (SIDE, self._gemm(GEMM_TN, wg_att, background=True)),
                       (SIDE, self._gemm(GEMM_NN, dg_kv)),
                       self._gemm(GEMM_NN, dg_q)]

@@ -218,12 +218,30 @@ def ln_fwd(dtype, probs, d, eps=1e-5) -> None:
         _lib.check(_lib.lib().bpm_ln_fwd(dtype, sub, k, d, eps, _stream()), "bpm_ln_fwd")
 
 
+_LN_WS = {}
+
+
+def _ln_workspace(n: int, d: int, device) -> torch.Tensor:
+    """Per-(device, stream) partial-sum workspace of bpm_ln_bwd_ws: launches on one stream are serialised, so they
+    can share it; the side stream gets its own."""
+    key = (str(device), _stream())
+    need = _lib.lib().bpm_ln_bwd_ws_bytes(n, d)
+    t = _LN_WS.get(key)
+    if t is None or t.numel() * 4 < need:
+        t = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+        _LN_WS[key] = t
+    return t
+
+
 def ln_bwd(probs, d, dtype=None, seed=0) -> None:
-    """dtype / seed only matter for problems with a fused `cast` output."""
+    """dtype / seed only matter for problems with a fused `cast` output.  Parameter / bias gradients go through a
+    partial-sum workspace (no float atomics)."""
     arr = _as_array(LnProblem, probs)
     dt = BPM_F32 if dtype is None else dtype
+    dev = torch.device("cuda", torch.cuda.current_device())
     for sub, k in _chunks(arr, LnProblem, None):
-        _lib.check(_lib.lib().bpm_ln_bwd(dt, sub, k, d, seed, _stream()), "bpm_ln_bwd")
+        ws = _ln_workspace(k, d, dev)
+        _lib.check(_lib.lib().bpm_ln_bwd_ws(dt, sub, k, d, seed, ws.data_ptr(), ws.numel() * 4, _stream()), "bpm_ln_bwd_ws")
 
 
 def cast_problem(a, lda, R, Cn, *, a_is_ct=False, b=None, ldb=0, dst_ct=None, ldd=0, ct_cols=0, dst_f32=None, ldf=0, colsum=None,

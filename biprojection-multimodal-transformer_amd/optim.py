@@ -83,6 +83,7 @@ class FusedAdam(torch.optim.Optimizer):
                                             g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                             self.step_count, grad_scale, int(self.fused_zero_grad),
                                             torch.cuda.current_stream().cuda_stream), "bpm_adam_step")
+        st.mark_dirty()                                    # masters changed through raw pointers: CT shadows are stale
         if self._tail_opt is not None:
             for tg in self._tail_opt.param_groups:
                 tg["lr"], tg["betas"], tg["eps"], tg["weight_decay"] = g["lr"], g["betas"], g["eps"], g["weight_decay"]

@@ -25,6 +25,7 @@
 #ifndef BPMULT_HIP_H
 #define BPMULT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -220,6 +221,11 @@ typedef struct bpm_ln_problem {
 } bpm_ln_problem;
 int bpm_ln_fwd(int dtype, const bpm_ln_problem* probs, int n, int d, float eps, void* stream);
 int bpm_ln_bwd(int dtype, const bpm_ln_problem* probs, int n, int d, uint64_t seed, void* stream);
+/* Same with a caller-provided workspace of at least bpm_ln_bwd_ws_bytes(n, d) bytes (16-byte aligned, private to the
+ * stream): dgamma / dbeta / cast_colsum are then produced by per-block partial rows and a second, single-owner pass
+ * (bitwise reproducible) instead of float atomics from every block into the same rows.  ws == NULL: as bpm_ln_bwd. */
+size_t bpm_ln_bwd_ws_bytes(int n, int d);
+int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* probs, int n, int d, uint64_t seed, void* ws, size_t ws_bytes, void* stream);
 
 /* y = (a [+ b]) * dropout_mult(r*C + c); a is fp32 or (a_is_ct) CT.  Outputs,
  * each optional: CT copy [R, ldd] (pad zeroed), fp32 copy, column sums (+= by

@@ -353,8 +353,52 @@ def f8_mmtrvapt():
     np.savez_compressed(path, **old)
 
 
+def f10_cfg3():
+    """BASELINE.json configs[2] dims: Moviescope-shape 4-modal `mmtrvapt`, d=768, 6 heads (head_dim 128), 5 layers,
+    orig_d_v=4096, L=512 / V=A=200 (biprojection level-2 encoders, time-axis maps, AudioEncoder front-end), B=1.
+    462 M parameters: the fixture keeps logits, gates, loss, every parameter's gradient norm and the full gradients of
+    the small tensors only (weights / inputs are regenerated from names)."""
+    pfx = "f10."
+    args = _args(hidden_sz=768, num_heads=6, layers=5, orig_d_l=768, orig_d_v=4096, orig_d_a=96, orig_d_p=4096, n_classes=13)
+    model = mmtr.MultiprojectionMMTransformerGMUClf(args)
+    model.train()
+    B = 1
+    xl, img = leaf(pfx + "xl", (B, 512, 768)), leaf(pfx + "img", (B, 200, 4096))
+    aud, post = leaf(pfx + "aud", (B, 96, 1000)), leaf(pfx + "post", (B, 4096))
+    model.enc.feat = xl
+    feat = {}
+
+    def _keep(mod, inp, o):
+        o.retain_grad()
+        feat["a"] = o
+
+    hook = model.audio_enc.register_forward_hook(_keep)
+    call = lambda: model(None, None, None, img, aud, post, output_gate=True)
+    full = ["out_layer.weight", "out_layer.bias", "proj2.bias", "transfm_l2v.bias", "transfm_a2l.bias",
+            "trans_l_with_a.layers.0.self_attn.in_proj_bias", "trans_a_with_v.layers.0.fc2.bias",
+            "trans_v_with_l2a.layers.0.layer_norms.0.weight", "trans_a_with_l2v.layers.1.layer_norms.1.bias",
+            "trans_l_with_v2a.layers.4.layer_norms.2.weight", "trans_a_with_v2l.layer_norm.weight",
+            "trans_v_with_l.layers.0.self_attn.out_proj.bias", "trans_l_with_a2v.layers.2.fc1.bias",
+            "trans_v_with_a2l.layers.3.self_attn.in_proj_bias", "audio_enc.conv_layers.0.bias", "audio_enc.conv_layers.1.bias"]
+    _model_fixture("f10_cfg3", model, pfx, call, {"post": post}, 13, full, small_only=True)
+    hook.remove()
+    path = os.path.join(HERE, "f10_cfg3.npz")
+    old = dict(np.load(path))
+    # input-side checks that stay small: gradient norms of the big inputs, the poster gradient in full, and a strided
+    # sample of the AudioEncoder output / its gradient
+    for k, t in (("xl", xl), ("img", img), ("aud", aud)):
+        g = t.grad.double()
+        old["ginn." + k] = np.array([g.norm().item(), g.sum().item()])
+    a = feat["a"]
+    old["audio_feat_s"] = a.detach().numpy()[:, ::8, ::5]
+    old["gin.audio_feat_s"] = a.grad.numpy()[:, ::8, ::5]
+    old["ginn.audio_feat"] = np.array([a.grad.double().norm().item(), a.grad.double().sum().item()])
+    np.savez_compressed(path, **old)
+    print(f"  f10_cfg3.npz now {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 ALL = dict(f1=f1_posemb, f2=f2_mask, f3=f3_mha, f4=f4_layer, f5=f5_encoder, f6=f6_gmu,
-           f7=f7_mmtrvat, f8=f8_mmtrvapt, f9=f9_cfg1)
+           f7=f7_mmtrvat, f8=f8_mmtrvapt, f9=f9_cfg1, f10=f10_cfg3)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

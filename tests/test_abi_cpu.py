@@ -23,7 +23,7 @@ def lib():
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(bpm_\w+)\s*\(", HEADER, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char\*)\s+(bpm_\w+)\s*\(", HEADER, flags=re.M))
     assert len(declared) >= 17
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:

@@ -87,6 +87,76 @@ def test_gemm_nt_bias_resid(dtype, M, N, K):
     close(out, ref, tol(dtype) if dtype == BPM_F32 else 2e-3, "nt")
 
 
+@pytest.mark.parametrize("variant", [GEMM_NT, GEMM_NN, GEMM_TN])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (520, 1536, 320), (4096, 3072, 768), (768, 3072, 1100), (300, 260, 512)])
+def test_gemm_large_tile_paths_bf16(variant, M, N, K):
+    """Shapes that the dispatcher sends to the LDS-DMA kernel (256 x 256 tiles; ragged M / N / K, K not a multiple of
+    the 64-k stage with zero-padded rows) and neighbours that stay on the 128 x 64 kernel: bias + residual epilogue,
+    bf16 operands, against fp64 on the bf16-rounded operands; in f32 mode the same shapes must agree too."""
+    for dtype in (BPM_BF16, BPM_F32):
+        pad64 = lambda n: (n + 63) // 64 * 64
+        if variant == GEMM_NT:
+            A, Ar = to_ct(rnd(M, K, seed=1), dtype, pad64(K)); Bm, Br = to_ct(rnd(N, K, seed=2, scale=K ** -0.5), dtype, pad64(K))
+            ref = Ar.double() @ Br.double().T
+        elif variant == GEMM_NN:
+            A, Ar = to_ct(rnd(M, K, seed=1), dtype, pad64(K)); Bm, Br = to_ct(rnd(K, N, seed=2, scale=K ** -0.5), dtype)
+            ref = Ar.double() @ Br.double()
+        else:
+            A, Ar = to_ct(rnd(K, M, seed=1), dtype); Bm, Br = to_ct(rnd(K, N, seed=2, scale=K ** -0.5), dtype)
+            ref = Ar.double().T @ Br.double()
+        bias = rnd(N, seed=3).to(DEV)
+        resid = rnd(M, N, seed=4).to(DEV)
+        out = torch.full((M, N), float("nan"), device=DEV)
+        cs = torch.zeros(M, device=DEV)
+        kw = dict(colsum_a=cs) if variant == GEMM_TN else {}
+        p = ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N, bias_n=bias, resid=resid, ldr=N, flags=ops.F_KPAD, **kw)
+        ops.gemm_grouped(dtype, variant, [p, p] if variant != GEMM_TN else [p])
+        close(out, ref + bias.cpu().double() + resid.cpu().double(), tol(dtype) if dtype == BPM_F32 else 2e-3, f"large tile v{variant}")
+        if variant == GEMM_TN:
+            close(cs, Ar.double().sum(0), 1e-4 if dtype == BPM_F32 else 2e-3, "colsum_a")
+
+
+def test_gemm_large_tile_epilogues_match_small_tile():
+    """Every fused epilogue through the LDS-DMA kernel (wide LDS-transposed stores) against the 128 x 64 kernel on the
+    same operands: relu + dropout -> CT, gate + column sums -> CT, head-major scatter (head_dim 128 and 64), += into f32.
+    The arithmetic per element is the same, so bf16 outputs may differ by one rounding of a differently ordered sum."""
+    import ctypes as C
+    from bpmult_amd import _lib
+    L = _lib.lib()
+    L.bpm_debug_gemm_force.argtypes = [C.c_int]
+    M, N, K = 1024, 768, 768
+    B_, ctt = 8, torch.bfloat16
+    A, _ = to_ct(rnd(M, K, seed=11), BPM_BF16, K)
+    W, _ = to_ct(rnd(N, K, seed=12, scale=K ** -0.5), BPM_BF16, K)
+    gate, _ = to_ct(rnd(M, N, seed=14), BPM_BF16, N)
+    bias = rnd(N, seed=13).to(DEV)
+    base = rnd(M, N, seed=15).to(DEV)
+    res = {}
+    try:
+        for cfg in (-2, 3, 2, 0):
+            _lib.check(L.bpm_debug_gemm_force(cfg), "force")
+            o1 = torch.full((M, N), float("nan"), device=DEV).to(ctt)
+            o2 = torch.full((M, N), float("nan"), device=DEV).to(ctt)
+            o3 = torch.zeros(B_, 6, M // B_, 128, device=DEV, dtype=ctt)
+            o4 = torch.zeros(B_, 12, M // B_, 64, device=DEV, dtype=ctt)
+            o5 = base.clone()
+            cs = torch.zeros(N, device=DEV)
+            ps = [ops.gemm_problem(A, W, o1, M, N, K, K, K, N, bias_n=bias, flags=F_RELU | ops.F_KPAD, drop_p=0.3, drop_site=5, out_kind=OUT_CT),
+                  ops.gemm_problem(A, W, o2, M, N, K, K, K, N, gate=gate, ldg=N, gate_scale=1.25, colsum=cs, flags=ops.F_KPAD, out_kind=OUT_CT),
+                  ops.gemm_problem(A, W, o3, M, N, K, K, K, 0, bias_n=bias, alpha=0.2, out_kind=OUT_HEADS, heads=(B_, 6, M // B_, 128, 128), flags=ops.F_KPAD),
+                  ops.gemm_problem(A, W, o4, M, N, K, K, K, 0, bias_n=bias, out_kind=OUT_HEADS, heads=(B_, 12, M // B_, 64, 64), flags=ops.F_KPAD),
+                  ops.gemm_problem(A, W, o5, M, N, K, K, K, N, flags=F_ACCUM | ops.F_KPAD)]
+            ops.gemm_grouped(BPM_BF16, GEMM_NT, ps, seed=77)
+            torch.cuda.synchronize()
+            res[cfg] = [t.float().cpu() for t in (o1, o2, o3, o4, o5, cs)]
+    finally:
+        L.bpm_debug_gemm_force(-1)
+    for cfg in (3, 2, 0):
+        for i, nm in enumerate(("relu+drop CT", "gate CT", "heads 128", "heads 64", "accum f32", "colsum")):
+            close(res[cfg][i], res[-2][i], 1e-2 if i < 4 else 2e-4, f"cfg {cfg} {nm}")
+        assert ((res[cfg][0] == 0) == (res[-2][0] == 0)).all(), "dropout / relu zero pattern must be identical"
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_gemm_nn_tn_and_splitk(dtype):
     M, N, K = 300, 140, 200          # dgrad: dx[M,K'] = dy[M,N'] W[N',K']; here generic names
@@ -159,7 +229,12 @@ def attn_ref(q, k, v, off, pmask):
                                                       (2, 2, 100, 70, 6, True, 0.0), (1, 2, 50, 50, 128, True, 0.0),
                                                       (1, 1, 33, 65, 64, False, 0.1), (1, 2, 2, 200, 25, True, 0.0),
                                                       (1, 1, 1, 1, 25, True, 0.0), (3, 1, 1, 5, 8, True, 0.0),
-                                                      (1, 2, 513, 512, 25, True, 0.0)])
+                                                      (1, 2, 513, 512, 25, True, 0.0),
+                                                      # head_dim 128 (hidden 768 / 6 heads, BASELINE configs[2]): multi-tile
+                                                      # forward / dQ / dK-dV paths, T > S (no mask), T < S (band), T = S + 1
+                                                      (1, 2, 512, 200, 128, True, 0.0), (1, 2, 200, 512, 128, True, 0.0),
+                                                      (1, 1, 513, 512, 128, True, 0.0), (1, 2, 512, 200, 128, True, 0.1),
+                                                      (1, 2, 200, 512, 128, True, 0.1), (1, 2, 512, 512, 64, True, 0.1)])
 def test_attention_fwd_bwd(dtype, B, H, T, S, dh, masked, pdrop):
     dhp = 32 if dh <= 32 else (64 if dh <= 64 else 128)
     ctt = ops.ct_torch(dtype)

