@@ -51,10 +51,25 @@ class GradSync:
         self._bytes = 0
         model._grad_ready_hook = self._on_ready
 
+    def _exchange(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        for a in range(lo, hi, self.bucket):
+            b = min(hi, a + self.bucket)
+            if self.compress == "bf16":
+                half = flat[a:b].to(torch.bfloat16)
+                self._half.append((half, flat[a:b]))
+                self.handles.append(dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._bytes += 2 * (b - a)
+            else:
+                self.handles.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._bytes += 4 * (b - a)
+
     def _on_ready(self, flat: torch.Tensor, lo: int, hi: int, events=None) -> None:
         """Called by the trunk's backward when gflat[lo:hi] is final for this step: once `events` have passed
         (a layer's slice: its main- and side-stream work), or everything launched on the current stream so far."""
         if self.world == 1 or not self.active:
+            return
+        if not flat.is_cuda:                 # host tensors (gloo rehearsal of the section protocol): no streams involved
+            self._exchange(flat, lo, hi)
             return
         if self.comm is None:
             self.comm = torch.cuda.Stream(device=flat.device)
@@ -64,16 +79,7 @@ class GradSync:
         else:
             self.comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm):
-            for a in range(lo, hi, self.bucket):
-                b = min(hi, a + self.bucket)
-                if self.compress == "bf16":
-                    half = flat[a:b].to(torch.bfloat16)
-                    self._half.append((half, flat[a:b]))
-                    self.handles.append(dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-                    self._bytes += 2 * (b - a)
-                else:
-                    self.handles.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-                    self._bytes += 4 * (b - a)
+            self._exchange(flat, lo, hi)
 
     def finish(self) -> None:
         """After loss.backward(): reduce the tail, wait for everything, apply (or hand on) 1/world."""
@@ -81,17 +87,24 @@ class GradSync:
             return
         st = self.model._store
         tail = [p.grad for n, p in self.model.named_parameters() if p.grad is not None and n not in st.params]
-        main = torch.cuda.current_stream()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record(main)
-        if self.comm is not None:
+        cuda = st.gflat.is_cuda
+        if cuda:
+            main = torch.cuda.current_stream()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+        if cuda and self.comm is not None:
             with torch.cuda.stream(self.comm):          # the communication stream waits for RCCL, the main stream for it
                 for h in self.handles:
                     h.wait()
                 for half, dst in self._half:
                     dst.copy_(half)
-            self._half.clear()
             main.wait_stream(self.comm)
+        else:
+            for h in self.handles:
+                h.wait()
+            for half, dst in self._half:
+                dst.copy_(half)
+        self._half.clear()
         self.handles.clear()
         inv = 1.0 / self.world
         if tail:
@@ -101,9 +114,10 @@ class GradSync:
                 flat.mul_(inv)
             for g, f in zip(tail, torch._utils._unflatten_dense_tensors(flat, tail)):
                 g.copy_(f)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record(main)
-        self._exposed.append((e0, e1))
+        if cuda:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(main)
+            self._exposed.append((e0, e1))
         if self.optimizer is not None:
             self.optimizer.pending_grad_scale = inv      # consumed (and reset) by the next FusedAdam.step()
         else:

@@ -24,12 +24,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                       # one GPU per rank over RCCL: the production path
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import bpmult_amd  # noqa: F401
     from bpmult_amd.distributed import GradSync
     from bpmult_amd.models import get_model
@@ -60,8 +64,22 @@ def _worker(rank, world, port, out):
     full = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     sync.active = True
     per = B // world
-    run(slice(rank * per, (rank + 1) * per))
-    sync.finish()
+    if backend == "nccl":
+        # with a gradient-accumulation micro-step in front (no exchange), each micro-step on half of the rank's shard:
+        # sum of the two half-shard mean-loss gradients / 2 == the shard's mean-loss gradient
+        half = per // 2
+        lo = rank * per
+        for p in model.parameters():
+            p.grad = None
+        for j, active in ((0, False), (1, True)):
+            sync.active = active
+            sl = slice(lo + j * half, lo + (j + 1) * half)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(model(xs[0][sl], None, None, xs[1][sl], xs[2][sl]), tgt[sl])
+            (loss / 2).backward()
+            sync.finish()
+    else:
+        run(slice(rank * per, (rank + 1) * per))
+        sync.finish()
     torch.cuda.synchronize()
     worst = 0.0
     for k, p in model.named_parameters():
@@ -81,6 +99,20 @@ def test_gradsync_two_ranks_equals_global_batch_gradient():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r, e in out.items():
+        assert e < 2e-4, (r, e)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the one-GPU box runs the gloo variant above")
+def test_gradsync_rccl_two_gpus_with_accumulation():
+    """backend "nccl" (= RCCL), one GPU per rank: per-layer slice all-reduces on the communication stream gated by main- and
+    side-stream events, prezero on the side stream beside in-flight exchanges, one accumulation micro-step."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out, "nccl"), nprocs=world, join=True)
     assert len(out) == world
     for r, e in out.items():
         assert e < 2e-4, (r, e)

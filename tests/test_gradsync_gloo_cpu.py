@@ -1,0 +1,108 @@
+"""distributed.GradSync itself on CPU (gloo, world_size 2): the section protocol the trunk's backward drives -- slices of
+the flat gradient buffer reported in reverse execution order and exchanged as they become final, bucket splitting,
+gradient-accumulation micro-steps that must NOT exchange (`active = False`), the flattened tail parameters, the
+1/world hand-off to an attached optimizer, and the opt-in bf16 compression."""
+import os
+import socket
+import sys
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Store:
+    """What GradSync needs of engine.ParamStore: the flat gradient buffer, the names it owns, its sections."""
+
+    def __init__(self, sizes):
+        self.params, self.off, off = {}, {}, 0
+        for n, k in sizes.items():
+            self.off[n] = off
+            off += k
+        self.total = off
+        self.gflat = torch.zeros(off)
+        self.params = {n: torch.nn.Parameter(torch.zeros(k)) for n, k in sizes.items()}
+        for n, p in self.params.items():
+            p.grad = self.gflat[self.off[n]: self.off[n] + p.numel()]
+        names = list(sizes)
+        self.sections = {n: (self.off[n], self.off[n] + sizes[n]) for n in names}
+
+
+class _Model(torch.nn.Module):
+    def __init__(self, sizes):
+        super().__init__()
+        self._store = _Store(sizes)
+        self.tail_w = torch.nn.Parameter(torch.zeros(5))
+        self.tail_b = torch.nn.Parameter(torch.zeros(3))
+        self._grad_ready_hook = None
+
+    def named_parameters(self, *a, **k):
+        yield from self._store.params.items()
+        yield "tail_w", self.tail_w
+        yield "tail_b", self.tail_b
+
+    def backward_like_the_trunk(self, contrib, tail):
+        """Accumulate this micro-step's gradients and report sections in reverse execution order."""
+        st = self._store
+        for n in ("fuse", "level2.layer1", "level2.layer0", "level1.layer0", "proj"):
+            lo, hi = st.sections[n]
+            st.gflat[lo:hi] += contrib[lo:hi]
+            if self._grad_ready_hook is not None:
+                self._grad_ready_hook(st.gflat, lo, hi, None)
+        for p, g in ((self.tail_w, tail[:5]), (self.tail_b, tail[5:])):
+            p.grad = g.clone() if p.grad is None else p.grad + g
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bpmult_amd  # noqa: F401
+    from bpmult_amd.distributed import GradSync
+    sizes = {"fuse": 300, "level2.layer1": 1000, "level2.layer0": 1000, "level1.layer0": 700, "proj": 130}
+    total = sum(sizes.values())
+    gen = lambda r, step: torch.randn(total + 8, generator=torch.Generator().manual_seed(100 * r + step))
+    res = {}
+    for mode in ("plain", "optimizer", "bf16"):
+        model = _Model(sizes)
+        opt = SimpleNamespace(pending_grad_scale=None) if mode == "optimizer" else None
+        sync = GradSync(model, bucket_bytes=4 * 256, optimizer=opt, compress="bf16" if mode == "bf16" else "none")
+        # two accumulation micro-steps: only the second one exchanges
+        for step, active in ((0, False), (1, True)):
+            sync.active = active
+            v = gen(rank, step)
+            model.backward_like_the_trunk(v[:total], v[total:])
+            sync.finish()
+            if not active:
+                assert not sync.handles and float((model._store.gflat - v[:total]).abs().max()) == 0.0
+        want = sum(gen(r, 0) + gen(r, 1) for r in range(world))
+        scale = 1.0 if mode == "optimizer" else 1.0 / world
+        got = torch.cat([model._store.gflat, model.tail_w.grad, model.tail_b.grad])
+        err = float((got - want * scale).abs().max() / want.abs().max())
+        if mode == "optimizer":
+            assert opt.pending_grad_scale == 1.0 / world
+        res[mode] = err
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_gradsync_sections_accumulation_tail_and_compression():
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert len(out) == world
+    for r, e in out.items():
+        assert e["plain"] < 1e-6 and e["optimizer"] < 1e-6, (r, e)
+        assert e["bf16"] < 2e-2, (r, e)          # one bf16 rounding of each summand and of the sum
