@@ -17,8 +17,8 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BPMULT_LIB", os.path.join(_HERE, "libbpmult_hip.so"))   # override: kernel-variant experiments
-SOURCES = ("gemm.hip", "attention.hip", "rowops.hip", "prof.hip")
-HEADERS = ("bpm_common.h", "bpm_prof.h")
+SOURCES = ("gemm.hip", "attention.hip", "rowops.hip", "tail.hip", "prof.hip")
+HEADERS = ("bpm_common.h", "bpm_prof.h", "gemm_dma.h")
 ARCH = "gfx950"
 PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5}
 
@@ -124,6 +124,23 @@ class GmuProblem(C.Structure):
                 ("ldg", C.c_int), ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("R", C.c_int)]
 
 
+class TailDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("d", C.c_int), ("n", C.c_int), ("C", C.c_int), ("N", C.c_int * 3),
+                ("top", C.c_void_p * 3), ("mid", C.c_void_p * 3), ("extra", C.c_void_p),
+                ("Wh", C.c_void_p * 4), ("Wg", C.c_void_p * 4),
+                ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("Wo", C.c_void_p), ("bo", C.c_void_p),
+                ("out_dropout", C.c_float), ("drop_site", C.c_uint32),
+                ("x", C.c_void_p), ("z", C.c_void_p), ("t", C.c_void_p), ("h", C.c_void_p), ("p1", C.c_void_p), ("y", C.c_void_p),
+                ("logits", C.c_void_p)]
+
+
+class TailGrads(C.Structure):
+    _fields_ = [("dlogits", C.c_void_p), ("dz", C.c_void_p), ("dWh", C.c_void_p * 4), ("dWg", C.c_void_p * 4),
+                ("dW1", C.c_void_p), ("db1", C.c_void_p), ("dW2", C.c_void_p), ("db2", C.c_void_p), ("dWo", C.c_void_p), ("dbo", C.c_void_p),
+                ("dtop", C.c_void_p * 3), ("dmid", C.c_void_p * 3), ("dextra", C.c_void_p),
+                ("dy", C.c_void_p), ("dp1", C.c_void_p), ("dh", C.c_void_p), ("dzp", C.c_void_p), ("dtp", C.c_void_p), ("dx", C.c_void_p)]
+
+
 _P, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
 
 # every symbol include/bpmult_hip.h declares: name -> argtypes
@@ -149,6 +166,8 @@ SIGNATURES = {
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
+    "bpm_tail_fwd": [C.POINTER(TailDesc), _U64, _P],
+    "bpm_tail_bwd": [C.POINTER(TailDesc), C.POINTER(TailGrads), _P],
     "bpm_adam_step": [_P, _P, _P, _P, C.c_size_t, _F, _F, _F, _F, _F, _I, _F, _I, _P],
     "bpm_stream_create": [_I, C.POINTER(C.c_void_p)],
     "bpm_stream_priority_range": [C.POINTER(_I), C.POINTER(_I)],

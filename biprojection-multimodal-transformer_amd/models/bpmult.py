@@ -4,11 +4,11 @@
 `MultiprojectionMMTransformerGMUClf` (4-modal, mmtr.py:277-583) keep the
 reference's constructor (`args`), forward signature and state_dict names.  The
 hot path -- temporal 1x1 projections, the twelve crossmodal / biprojection
-encoders, the dense Fusion-GMU layers, the time-axis maps -- runs as grouped
-HIP launches orchestrated by `_Trunk`; what the path hands to PyTorch is six
-[N,B,d] tensors (GMU "top" and "middle" per target modality).  The [B,d]-sized
-tail (token pick, final n-way GMU, residual head) and the front-ends upstream
-of the path (text encoder, AudioEncoder, poster projection) are ordinary
+encoders, the dense Fusion-GMU layers, the time-axis maps, and the [B,d] tail
+(level 1->3 residual + token pick, final n-way GMU, residual head) -- runs as
+grouped HIP launches orchestrated by `_Trunk` behind ONE autograd node
+(`_ModelFn`): features in, (logits, gates) out.  The front-ends upstream of
+the path (text encoder, AudioEncoder, poster projection) are ordinary
 PyTorch-ROCm modules.
 
 Deliberate departures from the reference's *behaviour as shipped* (all listed
@@ -22,11 +22,10 @@ import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .. import config, ops
-from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, CastProblem, GemmProblem, GmuProblem
+from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, CastProblem, GemmProblem, GmuProblem, TailDesc, TailGrads
 from ..engine import SITE_TEXT, EncoderDesc, EncoderGroupPlan, GroupCfg, ParamStore, register_encoder_shadows
 from ..ops import pad32
 from .encoder import TransformerEncoder
@@ -61,8 +60,9 @@ class GatedMultimodalLayerFeatures(nn.Module):
 
 
 class TextShiftingLayer(nn.Module):
-    """n-way gated fusion on [B,d] rows (TextShifting3Layer / TextShifting4Layer,
-    mmtr.py:197-247): sum_i sigmoid(G_i [x_1|..|x_n]) * tanh(W_i x_i)."""
+    """Parameters of the final n-way gated fusion on [B,d] rows (TextShifting3Layer / TextShifting4Layer,
+    mmtr.py:197-247): sum_i sigmoid(G_i [x_1|..|x_n]) * tanh(W_i x_i).  Evaluated by the tail kernels
+    (csrc/tail.hip, bpm_tail_fwd / bpm_tail_bwd); no PyTorch forward."""
 
     def __init__(self, sizes_in: Sequence[int], size_out: int):
         super().__init__()
@@ -71,15 +71,6 @@ class TextShiftingLayer(nn.Module):
             setattr(self, f"hidden{i}", nn.Linear(s, size_out, bias=False))
             setattr(self, f"x{i}_gate", nn.Linear(tot, size_out, bias=False))
         self.n = len(sizes_in)
-
-    def forward(self, xs):
-        cat = torch.cat(xs, dim=-1)
-        out, zs = 0, []
-        for i, x in enumerate(xs, 1):
-            z = torch.sigmoid(getattr(self, f"x{i}_gate")(cat))
-            out = out + z * torch.tanh(getattr(self, f"hidden{i}")(x))
-            zs.append(z)
-        return out, torch.cat(zs, dim=-1)
 
 
 class AudioEncoder(nn.Module):
@@ -179,6 +170,12 @@ class _Trunk:
                                            da2=z(R, self.ld, dt=ct), dag=z(R, self.ld, dt=ct), dx1=z(R, d), dx2=z(R, d))
         self._build_gmu()
         self._conv_cache = {}
+        # ---- [B,d] tail (token pick, final n-way GMU, residual head): activations kept for its backward + scratch
+        n = 4 if model.four_modal else 3
+        Cn = model.out_layer.out_features
+        self.tail = dict(n=n, C=Cn, **{k: z(B, n * d) for k in ("x", "z", "t", "dzp", "dtp", "dx")},
+                         **{k: z(B, d) for k in ("h", "p1", "y", "dy", "dp1", "dh")}, logits=z(B, Cn),
+                         dextra=z(B, d) if n == 4 else None)
 
     # -- temporal 1x1 projections (mmtr.py:456-469 / 748-761) -----------------------
     def conv_forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> None:
@@ -362,13 +359,65 @@ class _Trunk:
         self.gmu_forward()
         return [self.g[(t, k)]["out"] for t in ("l", "a", "v") for k in ("top", "mid")]
 
-    def backward(self, grads: Sequence[Optional[torch.Tensor]], seed: int, need_dx: Dict[str, bool]):
-        """grads: d(top_l), d(mid_l), d(top_a), d(mid_a), d(top_v), d(mid_v)."""
+    # -- [B,d] tail -------------------------------------------------------------------
+    TAIL_ORDER = ("l", "v", "a")                   # input order of the final GMU (mmtr.py:574, 857)
+
+    def tail_desc(self, extra: Optional[torch.Tensor], training: bool) -> TailDesc:
+        m, tl = self.m, self.tail
+        t = TailDesc()
+        t.B, t.d, t.n, t.C = self.B, self.d, tl["n"], tl["C"]
+        for i, k in enumerate(self.TAIL_ORDER):
+            t.N[i] = self.Ng[k]
+            t.top[i], t.mid[i] = self.g[(k, "top")]["out"].data_ptr(), self.g[(k, "mid")]["out"].data_ptr()
+        t.extra = extra.data_ptr() if extra is not None else None
+        for i in range(tl["n"]):
+            t.Wh[i] = getattr(m.gmu, f"hidden{i + 1}").weight.data_ptr()
+            t.Wg[i] = getattr(m.gmu, f"x{i + 1}_gate").weight.data_ptr()
+        t.W1, t.b1, t.W2, t.b2 = (x.data_ptr() for x in (m.proj1.weight, m.proj1.bias, m.proj2.weight, m.proj2.bias))
+        t.Wo, t.bo = m.out_layer.weight.data_ptr(), m.out_layer.bias.data_ptr()
+        t.out_dropout, t.drop_site = (m.out_dropout if training else 0.0), SITE_TEXT + 1
+        for k in ("x", "z", "t", "h", "p1", "y", "logits"):
+            setattr(t, k, tl[k].data_ptr())
+        return t
+
+    def tail_forward(self, extra: Optional[torch.Tensor], seed: int, training: bool):
+        self._tail_desc = self.tail_desc(extra, training)
+        ops.tail_fwd(self._tail_desc, seed)
+        return self.tail["logits"], self.tail["z"]
+
+    def tail_backward(self, dlogits: torch.Tensor, dz: Optional[torch.Tensor], params: Sequence[torch.Tensor]):
+        """Writes rows 0 / N-1 of the top / middle GMU output gradients (the trunk's `dout` buffers; their other rows
+        are never written and stay zero) and returns the tail parameters' gradients in the order of `params`
+        (model.tail_parameters()) plus the gradient of the 4th input."""
+        tl, n = self.tail, self.tail["n"]
+        gr = TailGrads()
+        gr.dlogits = dlogits.data_ptr()
+        gr.dz = dz.data_ptr() if dz is not None else None
+        grads = [torch.zeros_like(p) for p in params]        # accumulated into (+=) by the kernels
+        it = iter(grads)
+        for i in range(n):
+            gr.dWh[i] = next(it).data_ptr()
+        for i in range(n):
+            gr.dWg[i] = next(it).data_ptr()
+        gr.dW1, gr.db1, gr.dW2, gr.db2, gr.dWo, gr.dbo = (next(it).data_ptr() for _ in range(6))
+        for i, k in enumerate(self.TAIL_ORDER):
+            gr.dtop[i], gr.dmid[i] = self.g[(k, "top")]["dout"].data_ptr(), self.g[(k, "mid")]["dout"].data_ptr()
+        gr.dextra = tl["dextra"].data_ptr() if tl["dextra"] is not None else None
+        for k in ("dy", "dp1", "dh", "dzp", "dtp", "dx"):
+            setattr(gr, k, tl[k].data_ptr())
+        ops.tail_bwd(self._tail_desc, gr)
+        return grads, tl["dextra"]
+
+    def backward(self, grads: Optional[Sequence[Optional[torch.Tensor]]], seed: int, need_dx: Dict[str, bool]):
+        """grads: d(top_l), d(mid_l), d(top_a), d(mid_a), d(top_v), d(mid_v); None: the `dout` buffers of the GMU units
+        already hold them (written by tail_backward)."""
         st = self.st
         st.begin_backward()
-        it = iter(grads)
+        it = iter(grads) if grads is not None else None
         for t in ("l", "a", "v"):
             for k in ("top", "mid"):
+                if it is None:
+                    continue
                 g = next(it)
                 if g is None:
                     self.g[(t, k)]["dout"].zero_()
@@ -437,26 +486,36 @@ class _Trunk:
         return on_layer
 
 
-class _TrunkFn(torch.autograd.Function):
+class _ModelFn(torch.autograd.Function):
+    """The whole hot path as ONE autograd node: temporal projections, the twelve encoders, the Fusion-GMU units and the
+    [B,d] tail.  Inputs that can need a gradient: the three feature tensors, the optional 4th fusion input (poster
+    projection output) and the tail's parameters (PyTorch-owned; the trunk's live in the flat store)."""
+
     @staticmethod
-    def forward(ctx, anchor, x_l, x_v, x_a, model):
+    def forward(ctx, anchor, x_l, x_v, x_a, extra, model, *tail_params):
         trunk = model._trunk_for(x_l.shape[0])
         seed = model._next_seed()
         feats = {"l": x_l.detach().contiguous(), "v": x_v.detach().contiguous(), "a": x_a.detach().contiguous()}
-        outs = trunk.forward(feats, seed, model.training)
+        trunk.forward(feats, seed, model.training)
+        ex = extra.detach().contiguous() if extra is not None else None
+        logits, z = trunk.tail_forward(ex, seed, model.training)
         trunk.stamp = getattr(trunk, "stamp", 0) + 1
-        ctx.trunk, ctx.seed, ctx.stamp = trunk, seed, trunk.stamp
+        ctx.trunk, ctx.seed, ctx.stamp, ctx.extra, ctx.params = trunk, seed, trunk.stamp, ex, tail_params
         ctx.need = {"l": x_l.requires_grad, "v": x_v.requires_grad, "a": x_a.requires_grad}
-        return tuple(o.detach().clone() for o in outs)
+        return logits.detach().clone(), z.detach().clone()
 
     @staticmethod
-    def backward(ctx, *grads):
+    def backward(ctx, dlogits, dz):
         if ctx.stamp != ctx.trunk.stamp:
             # activations live in per-batch-size buffers owned by the model, not in the autograd graph
             raise RuntimeError("BPMulT hot path: backward() of a forward pass that a later forward pass (same model, same "
                                "batch size) has overwritten; run forward -> backward one step at a time")
-        res = ctx.trunk.backward(grads, ctx.seed, ctx.need)
-        return None, res["l"], res["v"], res["a"], None
+        dlogits = dlogits.contiguous().float()
+        dz = dz.contiguous().float() if dz is not None else None
+        pgrads, dextra = ctx.trunk.tail_backward(dlogits, dz, ctx.params)
+        res = ctx.trunk.backward(None, ctx.seed, ctx.need)
+        return (None, res["l"], res["v"], res["a"], dextra.clone() if (dextra is not None and ctx.extra is not None) else None,
+                None) + tuple(pgrads)
 
 
 class _BPMulTBase(nn.Module):
@@ -597,21 +656,22 @@ class _BPMulTBase(nn.Module):
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         return (torch.initial_seed() * 1000003 + rank * 0x9E3779B97F4A7C15 + int(self.dropout_step)) & 0xFFFFFFFFFFFFFFFF
 
-    def _fuse_and_head(self, outs, extra):
-        """[B,d]-sized tail: level 1->3 residual + first/last token (mmtr.py:806-808), final GMU, residual head."""
-        top_l, mid_l, top_a, mid_a, top_v, mid_v = outs
-        last = []
-        for top, mid in ((top_l, mid_l), (top_v, mid_v), (top_a, mid_a)):       # order (l, v, a), mmtr.py:857
-            tot = top + mid
-            last.append(tot[0] + tot[-1])
-        last_hs, z = self.gmu(last + extra)
-        y = self.proj2(F.dropout(F.relu(self.proj1(last_hs)), p=self.out_dropout, training=self.training)) + last_hs
-        return self.out_layer(y), z
+    def tail_parameters(self):
+        """The [B,d] tail's parameters in the order bpm_tail_bwd's gradients are returned."""
+        n = self.gmu.n
+        return ([getattr(self.gmu, f"hidden{i + 1}").weight for i in range(n)] + [getattr(self.gmu, f"x{i + 1}_gate").weight for i in range(n)]
+                + [self.proj1.weight, self.proj1.bias, self.proj2.weight, self.proj2.bias, self.out_layer.weight, self.out_layer.bias])
 
-    def _trunk(self, x_l, x_v, x_a):
+    def _run(self, x_l, x_v, x_a, extra):
+        """features -> (logits, gates) through the HIP path (one autograd node)."""
         self._ensure_store()
         self._want_grad = torch.is_grad_enabled()       # (grad mode is off inside autograd.Function.forward)
-        return _TrunkFn.apply(self._anchor, x_l.float(), x_v.float(), x_a.float(), self)
+        tail = self.tail_parameters()
+        for p in tail:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("BPMulT tail parameters must be contiguous float32")
+        return _ModelFn.apply(self._anchor, x_l.float(), x_v.float(), x_a.float(), extra.float() if extra is not None else None,
+                              self, *tail)
 
 
 class MultiprojectionMMTransformer3DGMUClf(_BPMulTBase):
@@ -631,8 +691,7 @@ class MultiprojectionMMTransformer3DGMUClf(_BPMulTBase):
 
     def forward(self, txt, mask, segment, img, audio, output_gate=False):
         x_l = self.enc(txt, mask, segment)                     # [B,L,orig_d_l]
-        outs = self._trunk(x_l, img, audio)
-        logits, z = self._fuse_and_head(outs, [])
+        logits, z = self._run(x_l, img, audio, None)
         return (logits, z) if output_gate else logits
 
 
@@ -656,6 +715,5 @@ class MultiprojectionMMTransformerGMUClf(_BPMulTBase):
     def forward(self, txt, mask, segment, img, audio, poster, output_gate=False):
         x_l = self.enc(txt, mask, segment)
         x_a = self.audio_enc(audio).transpose(1, 2)            # [B,96,A] -> [B,A,96]
-        outs = self._trunk(x_l, img, x_a)
-        logits, z = self._fuse_and_head(outs, [self.proj_poster(poster)])
+        logits, z = self._run(x_l, img, x_a, self.proj_poster(poster))
         return (logits, z) if output_gate else logits

@@ -280,3 +280,14 @@ def gmu2_bwd(dtype, probs, d) -> None:
     arr = _as_array(GmuProblem, probs)
     for sub, k in _chunks(arr, GmuProblem, None):
         _lib.check(_lib.lib().bpm_gmu2_bwd(dtype, sub, k, d, _stream()), "bpm_gmu2_bwd")
+
+
+# ----------------------------------------------------------------------------
+# [B,d] tail: token pick + n-way gated fusion + residual head
+# ----------------------------------------------------------------------------
+def tail_fwd(desc, seed: int = 0) -> None:
+    _lib.check(_lib.lib().bpm_tail_fwd(C.byref(desc), seed, _stream()), "bpm_tail_fwd")
+
+
+def tail_bwd(desc, grads) -> None:
+    _lib.check(_lib.lib().bpm_tail_bwd(C.byref(desc), C.byref(grads), _stream()), "bpm_tail_bwd")

@@ -256,6 +256,37 @@ typedef struct bpm_gmu_problem {
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
+/* The [B,d]-sized tail (all fp32, exact f32 VALU arithmetic from the fp32 master weights):
+ *   x_i   = (top_i + mid_i)[0] + (top_i + mid_i)[N_i - 1]            level 1 -> 3 residual + token pick, mmtr.py:806-808
+ *           (i = l, v, a in the order of mmtr.py:857); x_3 = extra (poster projection, 4-modal, mmtr.py:574)
+ *   z_i   = sigmoid(G_i [x_0|..|x_{n-1}]),  t_i = tanh(W_i x_i),  h = sum_i z_i t_i      TextShifting{3,4}Layer, mmtr.py:197-247
+ *   p1    = dropout(relu(proj1 h)),  y = proj2 p1 + h,  logits = out_layer y            mmtr.py:577-583 / 860-866
+ * top_i / mid_i are [N_i, B, d]; Wh[i] = gmu.hidden{i+1}.weight [d,d], Wg[i] = gmu.x{i+1}_gate.weight [d, n d].
+ * The forward keeps x, z, t, h, p1, y ([B, n d] or [B, d]) for the backward; z is the model's gate output. */
+typedef struct bpm_tail_desc {
+    int B, d, n, C;
+    int N[3];
+    const float* top[3]; const float* mid[3];
+    const float* extra;
+    const float* Wh[4]; const float* Wg[4];
+    const float* W1; const float* b1; const float* W2; const float* b2; const float* Wo; const float* bo;
+    float out_dropout; uint32_t drop_site;
+    float* x; float* z; float* t; float* h; float* p1; float* y; float* logits;
+} bpm_tail_desc;
+/* Backward: dlogits [B,C] (and optionally dz) in; parameter gradients are ACCUMULATED (+=) into dWh / dWg / dW1 / db1 / dW2 / db2 / dWo / dbo;
+ * rows 0 and N_i - 1 of dtop[i] / dmid[i] ([N_i,B,d], the other rows are never touched: keep them zero) and dextra
+ * [B,d] (NULL for n = 3) are WRITTEN; dy, dp1, dh [B,d] and dzp, dtp, dx [B, n d] are scratch. */
+typedef struct bpm_tail_grads {
+    const float* dlogits;
+    const float* dz;        /* gradient of the returned gates z [B, n d], or NULL */
+    float* dWh[4]; float* dWg[4];
+    float* dW1; float* db1; float* dW2; float* db2; float* dWo; float* dbo;
+    float* dtop[3]; float* dmid[3]; float* dextra;
+    float* dy; float* dp1; float* dh; float* dzp; float* dtp; float* dx;
+} bpm_tail_grads;
+int bpm_tail_fwd(const bpm_tail_desc* t, uint64_t seed, void* stream);
+int bpm_tail_bwd(const bpm_tail_desc* t, const bpm_tail_grads* g, void* stream);
+
 /* Fused Adam step over ONE flat fp32 buffer (replaces torch.optim.Adam's per-tensor loop of
  * train.py:123-125,396-398 for the trunk, whose parameters / gradients are views into flat buffers).
  * torch.optim.Adam semantics (no amsgrad, L2 weight decay folded into the gradient); `step` is the 1-based step

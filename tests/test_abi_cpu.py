@@ -44,14 +44,15 @@ def _c_fields(struct_name):
         first = parts[0].split()
         names.append(first[-1].lstrip("*"))
         names += [p.strip().lstrip("*") for p in parts[1:]]
-    return names
+    return [re.sub(r"\[\d+\]$", "", n) for n in names]
 
 
 @pytest.mark.parametrize("cname,cls", [("bpm_gemm_problem", _lib.GemmProblem), ("bpm_attn_problem", _lib.AttnProblem),
                                        ("bpm_pack_problem", _lib.PackProblem), ("bpm_pack_desc", _lib.PackDesc),
                                        ("bpm_embed_problem", _lib.EmbedProblem), ("bpm_ln_problem", _lib.LnProblem),
                                        ("bpm_cast_problem", _lib.CastProblem), ("bpm_gmu_problem", _lib.GmuProblem),
-                                       ("bpm_fold_desc", _lib.FoldDesc), ("bpm_unfold_desc", _lib.UnfoldDesc)])
+                                       ("bpm_fold_desc", _lib.FoldDesc), ("bpm_unfold_desc", _lib.UnfoldDesc),
+                                       ("bpm_tail_desc", _lib.TailDesc), ("bpm_tail_grads", _lib.TailGrads)])
 def test_ctypes_structs_mirror_the_header(cname, cls):
     assert _c_fields(cname) == [f[0] for f in cls._fields_]
 

@@ -596,3 +596,87 @@ def test_gemm_tn_colsum_of_first_operand(dtype):
     for i, (rc, rs) in enumerate(refs):
         close(keep[4 * i + 2], rc, tol(dtype) if dtype == BPM_F32 else 2e-3, "tn product")
         close(keep[4 * i + 3], rs, 1e-4 if dtype == BPM_F32 else 2e-3, "colsum_a")
+
+
+@pytest.mark.parametrize("n,B,d,Cn,Ns,pdrop", [(3, 2, 24, 6, (5, 7, 1), 0.0), (4, 5, 40, 13, (6, 3, 4), 0.0), (3, 11, 768, 6, (2, 2, 2), 0.3)])
+def test_tail_fwd_bwd_against_torch(n, B, d, Cn, Ns, pdrop):
+    """bpm_tail_fwd / bpm_tail_bwd (token pick + n-way gated fusion + residual head, mmtr.py:197-247, 806-808, 860-866)
+    against the same arithmetic in torch fp64 with autograd, including the gradient of the returned gates."""
+    from bpmult_amd._lib import TailDesc, TailGrads
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    top = [r(N, B, d) for N in Ns]
+    mid = [r(N, B, d) for N in Ns]
+    extra = r(B, d) if n == 4 else None
+    Wh = [r(d, d, sc=d ** -0.5) for _ in range(n)]
+    Wg = [r(d, n * d, sc=(n * d) ** -0.5) for _ in range(n)]
+    W1, b1, W2, b2, Wo, bo = r(d, d, sc=d ** -0.5), r(d), r(d, d, sc=d ** -0.5), r(d), r(Cn, d, sc=d ** -0.5), r(Cn)
+    dlog, dzv = r(B, Cn), r(B, n * d, sc=0.3)
+    leaves = [t.double().requires_grad_(True) for t in top + mid + ([extra] if n == 4 else []) + Wh + Wg + [W1, b1, W2, b2, Wo, bo]]
+    it = iter(leaves)
+    topr = [next(it) for _ in range(3)]
+    midr = [next(it) for _ in range(3)]
+    exr = next(it) if n == 4 else None
+    Whr = [next(it) for _ in range(n)]
+    Wgr = [next(it) for _ in range(n)]
+    W1r, b1r, W2r, b2r, Wor, bor = (next(it) for _ in range(6))
+    xs = [(topr[i] + midr[i])[0] + (topr[i] + midr[i])[-1] for i in range(3)] + ([exr] if n == 4 else [])
+    cat = torch.cat(xs, -1)
+    zs = [torch.sigmoid(cat @ Wgr[i].T) for i in range(n)]
+    h = sum(zs[i] * torch.tanh(xs[i] @ Whr[i].T) for i in range(n))
+    dm = drop_mult((B, d), pdrop, 21, (1 << 20) + 1).double()
+    p1 = torch.relu(h @ W1r.T + b1r) * dm
+    y = p1 @ W2r.T + b2r + h
+    logits = y @ Wor.T + bor
+    zcat = torch.cat(zs, -1)
+    ((logits * dlog.double()).sum() + (zcat * dzv.double()).sum()).backward()
+
+    dev = lambda t: t.to(DEV).contiguous()
+    keep = dict(top=[dev(t) for t in top], mid=[dev(t) for t in mid], extra=dev(extra) if n == 4 else None,
+                Wh=[dev(t) for t in Wh], Wg=[dev(t) for t in Wg], misc=[dev(t) for t in (W1, b1, W2, b2, Wo, bo)])
+    z_ = lambda *s: torch.zeros(*s, device=DEV)
+    buf = {k: z_(B, n * d) for k in ("x", "z", "t", "dzp", "dtp", "dx")}
+    buf.update({k: z_(B, d) for k in ("h", "p1", "y", "dy", "dp1", "dh")})
+    buf["logits"] = z_(B, Cn)
+    t = TailDesc()
+    t.B, t.d, t.n, t.C = B, d, n, Cn
+    for i in range(3):
+        t.N[i], t.top[i], t.mid[i] = Ns[i], keep["top"][i].data_ptr(), keep["mid"][i].data_ptr()
+    t.extra = keep["extra"].data_ptr() if n == 4 else None
+    for i in range(n):
+        t.Wh[i], t.Wg[i] = keep["Wh"][i].data_ptr(), keep["Wg"][i].data_ptr()
+    t.W1, t.b1, t.W2, t.b2, t.Wo, t.bo = (x.data_ptr() for x in keep["misc"])
+    t.out_dropout, t.drop_site = pdrop, (1 << 20) + 1
+    for k in ("x", "z", "t", "h", "p1", "y", "logits"):
+        setattr(t, k, buf[k].data_ptr())
+    ops.tail_fwd(t, 21)
+    tl = 2e-5
+    close(buf["logits"], logits.detach(), tl, "logits")
+    close(buf["z"], zcat.detach(), tl, "gates")
+    gr = TailGrads()
+    dl, dzd = dev(dlog), dev(dzv)
+    gr.dlogits, gr.dz = dl.data_ptr(), dzd.data_ptr()
+    gW = dict(Wh=[1 + z_(d, d) for _ in range(n)], Wg=[1 + z_(d, n * d) for _ in range(n)],
+              misc=[1 + z_(*s) for s in ((d, d), (d,), (d, d), (d,), (Cn, d), (Cn,))])       # += semantics: start from ones
+    for i in range(n):
+        gr.dWh[i], gr.dWg[i] = gW["Wh"][i].data_ptr(), gW["Wg"][i].data_ptr()
+    gr.dW1, gr.db1, gr.dW2, gr.db2, gr.dWo, gr.dbo = (x.data_ptr() for x in gW["misc"])
+    dtop, dmid = [z_(N, B, d) for N in Ns], [z_(N, B, d) for N in Ns]
+    dex = z_(B, d) if n == 4 else None
+    for i in range(3):
+        gr.dtop[i], gr.dmid[i] = dtop[i].data_ptr(), dmid[i].data_ptr()
+    gr.dextra = dex.data_ptr() if n == 4 else None
+    for k in ("dy", "dp1", "dh", "dzp", "dtp", "dx"):
+        setattr(gr, k, buf[k].data_ptr())
+    ops.tail_bwd(t, gr)
+    tg = 1e-4
+    for i in range(3):
+        close(dtop[i], topr[i].grad, tg, f"dtop{i}")
+        close(dmid[i], midr[i].grad, tg, f"dmid{i}")
+    if n == 4:
+        close(dex, exr.grad, tg, "dextra")
+    for i in range(n):
+        close(gW["Wh"][i] - 1, Whr[i].grad, tg, f"dWh{i}")
+        close(gW["Wg"][i] - 1, Wgr[i].grad, tg, f"dWg{i}")
+    for nm, got, ref in zip(("dW1", "db1", "dW2", "db2", "dWo", "dbo"), gW["misc"], (W1r, b1r, W2r, b2r, Wor, bor)):
+        close(got - 1, ref.grad, tg, nm)
