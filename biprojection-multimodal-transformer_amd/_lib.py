@@ -17,10 +17,10 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BPMULT_LIB", os.path.join(_HERE, "libbpmult_hip.so"))   # override: kernel-variant experiments
-SOURCES = ("gemm.hip", "attention.hip", "rowops.hip", "tail.hip", "prof.hip")
+SOURCES = ("gemm.hip", "attention.hip", "xblock.hip", "rowops.hip", "tail.hip", "prof.hip")
 HEADERS = ("bpm_common.h", "bpm_prof.h", "gemm_dma.h")
 ARCH = "gfx950"
-PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5}
+PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5, "xblock": 6}
 
 BPM_F32, BPM_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
@@ -124,6 +124,15 @@ class GmuProblem(C.Structure):
                 ("ldg", C.c_int), ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("R", C.c_int)]
 
 
+class XBlockProblem(C.Structure):
+    _fields_ = [("xq", C.c_void_p), ("xk", C.c_void_p), ("xv", C.c_void_p),
+                ("Wq", C.c_void_p), ("bq", C.c_void_p), ("Wk", C.c_void_p), ("bk", C.c_void_p), ("Wv", C.c_void_p), ("bv", C.c_void_p),
+                ("Wo", C.c_void_p), ("bo", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
+                ("qh", C.c_void_p), ("kh", C.c_void_p), ("vh", C.c_void_p), ("ao", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("S", C.c_int), ("d", C.c_int), ("ld", C.c_int), ("mask_off", C.c_int),
+                ("scale", C.c_float), ("attn_drop", C.c_float), ("attn_site", C.c_uint32), ("res_drop", C.c_float), ("res_site", C.c_uint32)]
+
+
 class TailDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("d", C.c_int), ("n", C.c_int), ("C", C.c_int), ("N", C.c_int * 3),
                 ("top", C.c_void_p * 3), ("mid", C.c_void_p * 3), ("extra", C.c_void_p),
@@ -166,6 +175,7 @@ SIGNATURES = {
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
+    "bpm_xblock_fwd": [_I, C.POINTER(XBlockProblem), _I, _U64, _P],
     "bpm_tail_fwd": [C.POINTER(TailDesc), _U64, _P],
     "bpm_tail_bwd": [C.POINTER(TailDesc), C.POINTER(TailGrads), _P],
     "bpm_adam_step": [_P, _P, _P, _P, C.c_size_t, _F, _F, _F, _F, _F, _I, _F, _I, _P],

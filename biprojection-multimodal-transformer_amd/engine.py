@@ -32,9 +32,9 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
-from ._lib import (F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
+from ._lib import (BPM_BF16, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
                    AttnProblem, CastProblem, FoldDesc, GemmProblem, LnProblem, PackDesc,
-                   UnfoldDesc)
+                   UnfoldDesc, XBlockProblem)
 from .ops import pad32
 
 # dropout site ids (unique per encoder / layer / op; the seed changes per step)
@@ -300,6 +300,13 @@ class GroupCfg:
 
 
 SIDE, JOIN, MARK, WAIT, SIDE2 = "side", "join", "mark", "wait", "side2"
+# Short sequences (T, S <= 64) at head_dim 128 in bf16: the crossmodal attention block of a layer (Q / K / V
+# projections, attention, output projection + residual) CAN run as ONE launch (csrc/xblock.hip) instead of five.
+# Off by default: measured on MI355X at the kernel point (d=768, H=6, T=S=50, B=64, six encoders; tools/kernel_point.py)
+# the fused launch takes 464 us against 216 us for the separate kernels -- one 64-row workgroup per (encoder, batch
+# element) issues six LDS-DMA instructions per 16 MFMAs and is paced by their issue cost, where the grouped GEMMs spread
+# the same weight traffic over 3200-row problems.  tools/kernel_point.py and the tests flip it.
+FUSE_SHORT_BLOCKS = False
 _SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
 # dK/dV attention pass: "0" main stream, "1" side stream, "2" a third stream, "auto": side stream at hidden >= 512.
 # dK / dV feed only side-stream work (weight gradients, key/value dgrad).  At hidden 300 the side stream is the longer
@@ -423,6 +430,8 @@ class EncoderGroupPlan:
                 ud.append(u)
             self._unfold.append((ops.device_table(ud), len(ud), blk))
         self._dkv_side = _DKV_SIDE_ENV if _DKV_SIDE_ENV != "auto" else ("1" if d >= 512 else "0")
+        self.fused_block = (FUSE_SHORT_BLOCKS and self.dtype == BPM_BF16 and self.dh == 128 and self.ld == d
+                            and all(e.T <= 64 and e.S <= 64 and e.T_full is None for e in self.encs))
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
         self._bwd = {True: self._build_bwd(True), False: self._build_bwd(False)}
 
@@ -452,10 +461,10 @@ class EncoderGroupPlan:
         for e, b in zip(self.encs, self.buf):
             hat += [ops.ln_problem(b["ke"], self._ones, self._zeros, b["stk"][0], b["stk"][1], b["Rk"], out=b["khat"], ldo=ld),
                     ops.ln_problem(b["ve"], self._ones, self._zeros, b["stv"][0], b["stv"][1], b["Rk"], out=b["vhat"], ldo=ld)]
-        steps, kv_steps = [], [(SIDE, (ops.ln_fwd, self.dtype, A(LnProblem, hat), d))]
+        steps, kv_steps = [], [(SIDE, (ops.ln_fwd, self.dtype, A(LnProblem, hat), d)), (MARK, "hat")]
         for i in range(c.layers):
             ln, qkv, att, outp, ln2, fc1, fc2 = [], [], [], [], [], [], []
-            kvp = []
+            kvp, xblk = [], []
             pre = dict(ln=[], qkv=[], att=[], outp=[], cast=[])      # biprojection self-attention half
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -498,6 +507,14 @@ class EncoderGroupPlan:
                     q_src, resid_src = b["xn"][i], x_in
                     gf, bf = g1, b1
                     stf = (b["st1m"][i], b["st1r"][i])
+                if self.fused_block:
+                    kvf = self._pn(e, i, KVF)
+                    xblk.append(ops.xblock_problem(
+                        q_src, b["khat"], b["vhat"], st.sptr(ipw, 0), ipb[:d], st.sptr(kvf, 0), st.fold(kvf, 0, d),
+                        st.sptr(kvf, d * ld), st.fold(kvf, d, d), st.sptr(wo), P("self_attn.out_proj.bias"), resid_src, b["xmid"][i],
+                        b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, d, ld,
+                        self._mask_off(e.T, e.S), self.scale, attn_drop=pr(e.attn_dropout), attn_site=site(e.enc_id, i, S_ATTN),
+                        res_drop=pr(c.res_dropout), res_site=site(e.enc_id, i, S_RES1)))
                 qkv.append(proj(q_src, R, 0, b["qh"][i], e.T))
                 kvp.append(proj_kv(b["khat"], 1, b["kh"][i]))
                 kvp.append(proj_kv(b["vhat"], 2, b["vh"][i]))
@@ -522,14 +539,18 @@ class EncoderGroupPlan:
                           (ops.rows_cast, self.dtype, A(CastProblem, pre["cast"]))]
             # K/V side of every layer depends only on the (embedded) key/value sources: the side stream runs it
             # ahead of the query chain; the main stream waits for layer i's K/V heads just before attention i.
-            kv_steps += [(SIDE, self._gemm(GEMM_NT, kvp)), (MARK, i)]
+            if not self.fused_block:
+                kv_steps += [(SIDE, self._gemm(GEMM_NT, kvp)), (MARK, i)]
             if ln:
                 steps.append((ops.ln_fwd, self.dtype, A(LnProblem, ln), d))
-            steps += [self._gemm(GEMM_NT, qkv),
-                      (WAIT, i),
-                      (ops.attn_fwd, self.dtype, A(AttnProblem, att)),
-                      self._gemm(GEMM_NT, outp),
-                      (ops.ln_fwd, self.dtype, A(LnProblem, ln2), d),
+            if self.fused_block:       # one launch: projections + attention + output projection + residual
+                steps += [(WAIT, "hat"), (ops.xblock_fwd, self.dtype, A(XBlockProblem, xblk))]
+            else:
+                steps += [self._gemm(GEMM_NT, qkv),
+                          (WAIT, i),
+                          (ops.attn_fwd, self.dtype, A(AttnProblem, att)),
+                          self._gemm(GEMM_NT, outp)]
+            steps += [(ops.ln_fwd, self.dtype, A(LnProblem, ln2), d),
                       self._gemm(GEMM_NT, fc1),
                       self._gemm(GEMM_NT, fc2)]
         fin = [ops.ln_problem(b["x"][c.layers], st.p(e.prefix + "layer_norm.weight"), st.p(e.prefix + "layer_norm.bias"),
@@ -542,7 +563,7 @@ class EncoderGroupPlan:
         fn = s[0]
         if fn is ops.gemm_grouped:
             fn(s[1], s[2], s[3], seed)
-        elif fn in (ops.attn_fwd, ops.attn_bwd, ops.attn_bwd_dq, ops.attn_bwd_dkv, ops.rows_cast):
+        elif fn in (ops.attn_fwd, ops.attn_bwd, ops.attn_bwd_dq, ops.attn_bwd_dkv, ops.rows_cast, ops.xblock_fwd):
             fn(s[1], s[2], seed)
         elif fn is ops.ln_fwd:
             fn(s[1], s[2], s[3])

@@ -256,6 +256,26 @@ typedef struct bpm_gmu_problem {
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
+/* Fused crossmodal-attention block, forward, for short sequences: T, S <= 64, head_dim 128 (d = 128 H), BPM_BF16 only
+ * (anything else: BPM_ERR_ARG -- run the separate kernels).  One launch replaces Q / K / V projections + attention +
+ * output projection (multihead_attention.py:82-130 with the residual dropout + add of transformer.py:157-175):
+ *   Q = (xq Wq^T + bq) scale, K = xk Wk^T + bk, V = xv Wv^T + bv, O = dropout(softmax_fp32(Q_h K_h^T + mask)) V_h,
+ *   out = resid + dropout(O Wo^T + bo).
+ * xq [T*B, ld] is the normalised query source, xk / xv [S*B, ld] the normalised key / value sources (CT = bf16, rows
+ * t*B + b, ld == d); Wq / Wk / Wv / Wo are CT [d, ld] (LayerNorm gain / bias of the key / value side folded in by the
+ * caller), biases fp32 [d].  Saved for the backward kernels exactly as the separate path saves them: qh [B,H,T,128],
+ * kh / vh [B,H,S,128], ao [T*B, ldo] (ldo == ld), lse [B,H,T].  Key j is visible to query i iff j - i < mask_off. */
+typedef struct bpm_xblock_problem {
+    const void* xq; const void* xk; const void* xv;
+    const void* Wq; const float* bq; const void* Wk; const float* bk; const void* Wv; const float* bv; const void* Wo; const float* bo;
+    const float* resid; float* out;
+    void* qh; void* kh; void* vh; void* ao; int ldo; float* lse;
+    int B, H, T, S, d, ld, mask_off;
+    float scale;
+    float attn_drop; uint32_t attn_site; float res_drop; uint32_t res_site;
+} bpm_xblock_problem;
+int bpm_xblock_fwd(int dtype, const bpm_xblock_problem* probs, int n, uint64_t seed, void* stream);
+
 /* The [B,d]-sized tail (all fp32, exact f32 VALU arithmetic from the fp32 master weights):
  *   x_i   = (top_i + mid_i)[0] + (top_i + mid_i)[N_i - 1]            level 1 -> 3 residual + token pick, mmtr.py:806-808
  *           (i = l, v, a in the order of mmtr.py:857); x_3 = extra (poster projection, 4-modal, mmtr.py:574)
@@ -311,7 +331,7 @@ int bpm_stream_priority_range(int* least, int* greatest);
  * per-launch durations (ms), work and launch count of one kind, and clears them.
  * ---------------------------------------------------------------------- */
 enum { BPM_PROF_GEMM_NT = 0, BPM_PROF_GEMM_NN = 1, BPM_PROF_GEMM_TN = 2, BPM_PROF_ATTN_FWD = 3,
-       BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5 };
+       BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5, BPM_PROF_XBLOCK = 6 };
 int bpm_prof_enable(unsigned kind_mask);
 int bpm_prof_collect(int kind, double* total_ms, double* total_work, int* launches);
 

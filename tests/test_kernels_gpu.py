@@ -680,3 +680,64 @@ def test_tail_fwd_bwd_against_torch(n, B, d, Cn, Ns, pdrop):
         close(gW["Wg"][i] - 1, Wgr[i].grad, tg, f"dWg{i}")
     for nm, got, ref in zip(("dW1", "db1", "dW2", "db2", "dWo", "dbo"), gW["misc"], (W1r, b1r, W2r, b2r, Wor, bor)):
         close(got - 1, ref.grad, tg, nm)
+
+
+@pytest.mark.parametrize("B,T,S,masked,pa,pr", [(5, 50, 50, True, 0.0, 0.0), (3, 40, 64, True, 0.1, 0.1), (2, 64, 33, True, 0.0, 0.2),
+                                                  (4, 50, 50, False, 0.1, 0.0), (1, 1, 7, True, 0.0, 0.0)])
+def test_fused_crossmodal_block_matches_separate_kernels(B, T, S, masked, pa, pr):
+    """bpm_xblock_fwd (Q/K/V projections + attention + output projection + residual in one launch; hidden 768, 6 heads
+    of 128, T, S <= 64) against (a) the separate HIP kernels it replaces, same dropout sites and seed, on every tensor it
+    produces or saves for backward, and (b) fp64 torch on the bf16-rounded operands at dropout 0."""
+    H, dh, d = 6, 128, 768
+    ct = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    rb = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(ct)
+    xq, xk, xv = rb(T * B, d), rb(S * B, d), rb(S * B, d)
+    Wq, Wk, Wv, Wo = (rb(d, d, sc=d ** -0.5) for _ in range(4))
+    bq, bk, bv, bo = (torch.randn(d, generator=g) * 0.1 for _ in range(4))
+    resid = torch.randn(T * B, d, generator=g)
+    scale = dh ** -0.5
+    off = 1 + abs(S - T) if masked else (1 << 30)
+    D = lambda t: t.to(DEV).contiguous()
+    dev = {k: D(v) for k, v in dict(xq=xq, xk=xk, xv=xv, Wq=Wq, Wk=Wk, Wv=Wv, Wo=Wo, bq=bq, bk=bk, bv=bv, bo=bo, resid=resid).items()}
+
+    def bufs():
+        return dict(qh=torch.zeros(B, H, T, dh, device=DEV, dtype=ct), kh=torch.zeros(B, H, S, dh, device=DEV, dtype=ct),
+                    vh=torch.zeros(B, H, S, dh, device=DEV, dtype=ct), ao=torch.zeros(T * B, d, device=DEV, dtype=ct),
+                    lse=torch.zeros(B, H, T, device=DEV), out=torch.full((T * B, d), float("nan"), device=DEV))
+
+    # (a) separate kernels
+    u = bufs()
+    proj = lambda x, W, b_, dst, L, alpha: ops.gemm_problem(dev[x], dev[W], dst, L * B, d, d, d, d, 0, bias_n=dev[b_], alpha=alpha,
+                                                            out_kind=OUT_HEADS, heads=(B, H, L, dh, dh), flags=ops.F_KPAD)
+    ops.gemm_grouped(BPM_BF16, GEMM_NT, [proj("xq", "Wq", "bq", u["qh"], T, scale), proj("xk", "Wk", "bk", u["kh"], S, 1.0),
+                                         proj("xv", "Wv", "bv", u["vh"], S, 1.0)], 31)
+    ops.attn_fwd(BPM_BF16, [ops.attn_problem(u["qh"], u["kh"], u["vh"], u["ao"], d, u["lse"], B, H, T, S, dh, dh, off, drop_p=pa, drop_site=9)], 31)
+    ops.gemm_grouped(BPM_BF16, GEMM_NT, [ops.gemm_problem(u["ao"], dev["Wo"], u["out"], T * B, d, d, d, d, d, bias_n=dev["bo"],
+                                                          resid=dev["resid"], ldr=d, drop_p=pr, drop_site=11, flags=ops.F_KPAD)], 31)
+    # fused
+    f = bufs()
+    p = ops.xblock_problem(dev["xq"], dev["xk"], dev["xv"], dev["Wq"], dev["bq"], dev["Wk"], dev["bk"], dev["Wv"], dev["bv"], dev["Wo"], dev["bo"],
+                           dev["resid"], f["out"], f["qh"], f["kh"], f["vh"], f["ao"], d, f["lse"], B, H, T, S, d, d, off, scale,
+                           attn_drop=pa, attn_site=9, res_drop=pr, res_site=11)
+    ops.xblock_fwd(BPM_BF16, [p, p] if B == 1 else [p], 31)
+    torch.cuda.synchronize()
+    for k in ("qh", "kh", "vh"):
+        close(f[k].float(), u[k].float().cpu(), 8e-3, k)          # one bf16 ulp of a differently ordered k sum
+    close(f["lse"], u["lse"].cpu(), 2e-2, "lse")
+    close(f["ao"].float(), u["ao"].float().cpu(), 2e-2, "ao")
+    close(f["out"], u["out"].cpu(), 3e-2, "out")
+    if pr > 0:
+        dropped = lambda t: ((t - dev["resid"]).abs() < 1e-12)
+        assert (dropped(f["out"]) == dropped(u["out"])).float().mean() > 0.999, "residual-dropout mask must be the same"
+    # (b) fp64 reference, dropout 0
+    if pa == 0 and pr == 0:
+        X = lambda t, L: t.double().reshape(L, B, d)
+        q = ((X(xq, T) @ Wq.double().T + bq.double()) * scale).to(ct).double().reshape(T, B, H, dh).permute(1, 2, 0, 3)
+        k_ = (X(xk, S) @ Wk.double().T + bk.double()).to(ct).double().reshape(S, B, H, dh).permute(1, 2, 0, 3)
+        v_ = (X(xv, S) @ Wv.double().T + bv.double()).to(ct).double().reshape(S, B, H, dh).permute(1, 2, 0, 3)
+        o_ref, lse_ref = attn_ref(q, k_, v_, off if masked else 0, torch.ones(B, H, T, S, dtype=torch.float64))
+        o_rows = o_ref.permute(2, 0, 1, 3).reshape(T * B, d)
+        out_ref = o_rows.to(ct).double() @ Wo.double().T + bo.double() + resid.double()
+        close(f["lse"], lse_ref, 2e-2, "lse vs fp64")
+        close(f["out"], out_ref, 3e-2, "out vs fp64")

@@ -336,3 +336,75 @@ def test_input_longer_than_num_vectors_is_rejected():
         m(x[0], None, None, too_long, x[2])
     with torch.no_grad():                                      # exactly the maximum is fine
         m(x[0], None, None, torch.randn(2, 48, 35, device="cuda"), x[2])
+
+
+def _prop_args(model, **kw):
+    a = args_for(model, **kw)
+    a.text_features = True
+    return a
+
+
+def _randn(*s, seed):
+    return torch.randn(*s, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("name", ["cfg4_mosei_b64", "cfg5_stress_d1536"])
+def test_full_size_configs_properties(name):
+    """BASELINE.json configs[3] (CMU-MOSEI shape: 3-modal, d=300, 12 heads, 8 layers, L/V/A = 50/500/500 -> 512, the
+    per-GPU batch of 64) and configs[4] (stress: 4-modal, d=1536, 12 heads -> head_dim 128, seq_len 512 per modality,
+    5 layers) at FULL size through the HIP path, bf16.  The reference cannot be run at these sizes in a test, so the
+    checks are size-independent properties of the model: finite outputs of the right shape; train mode with every
+    dropout rate 0 equals eval mode exactly (the only train/eval difference is dropout); gradients accumulate (two
+    backward passes without clearing == twice one pass); parameters the graph never touches get no gradient; and rows of
+    the batch are independent (the first sample alone gives the same logits as inside the batch)."""
+    if name == "cfg4_mosei_b64":
+        a = _prop_args("mmtrvat")                          # d=300, H=12, 8 layers, lengths padded to 512
+        B = 64
+        ins = [_randn(B, 50, 768, seed=1), _randn(B, 500, 35, seed=2), _randn(B, 500, 74, seed=3)]
+        nc, unused = 6, ("transfm_",)
+    else:
+        a = _prop_args("mmtrvapt", hidden_sz=1536, num_heads=12, layers=5, orig_d_l=768, orig_d_v=4096, orig_d_a=96, orig_d_p=4096,
+                       n_classes=13, num_vectors_l=512, num_vectors_a=512, num_vectors_v=512)
+        B = 2
+        ins = [_randn(B, 512, 768, seed=1), _randn(B, 512, 4096, seed=2), _randn(B, 96, 2600, seed=3), _randn(B, 4096, seed=4)]
+        nc, unused = 13, ()
+    torch.manual_seed(3)
+    model = get_model(a)
+    if name == "cfg5_stress_d1536":
+        # AudioEncoder ends in AdaptiveAvgPool1d(200) (mmtr.py:93-108): the 512-vector override needs a 512-long audio
+        # feature sequence, so the stress shape pools to num_vectors_a
+        model.audio_enc.conv_layers[2] = torch.nn.AdaptiveAvgPool1d(512)
+    model.precision = "bf16"
+    model = model.cuda()
+    dev = [t.cuda() for t in ins]
+    call = lambda m, xs: m(xs[0], None, None, *xs[1:])
+    tgt = (_randn(B, nc, seed=9) > 0).float().cuda()
+
+    model.train()
+    out_train = call(model, dev)
+    assert out_train.shape == (B, nc) and torch.isfinite(out_train).all()
+    model.eval()
+    with torch.no_grad():
+        out_eval = call(model, dev)
+        one = call(model, [t[:1] for t in dev])
+    assert torch.equal(out_train.detach(), out_eval), "dropout 0: train == eval"
+    e1 = float((one[0] - out_eval[0]).abs().max() / out_eval.abs().max().clamp_min(1e-6))
+    assert e1 < 2e-2, f"batch rows are independent: {e1:.3e}"
+
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    torch.nn.functional.binary_cross_entropy_with_logits(call(model, dev), tgt).backward()
+    g1 = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    for k, p in model.named_parameters():
+        if k.startswith(unused) or (k == "proj_l.weight" and a.orig_d_l == a.hidden_sz):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    torch.nn.functional.binary_cross_entropy_with_logits(call(model, dev), tgt).backward()      # accumulate on top
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k not in g1 or float(g1[k].abs().max()) == 0.0:
+            continue
+        worst = max(worst, float((p.grad - 2 * g1[k]).abs().max() / (2 * g1[k].abs().max())))
+    assert worst < 2e-3, f"gradient accumulation identity: {worst:.3e}"
