@@ -17,7 +17,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BPMULT_LIB", os.path.join(_HERE, "libbpmult_hip.so"))   # override: kernel-variant experiments
-SOURCES = ("gemm.hip", "attention.hip", "xblock.hip", "rowops.hip", "tail.hip", "prof.hip")
+SOURCES = ("gemm.hip", "attention.hip", "xblock.hip", "rowops.hip", "tail.hip", "frontend.hip", "prof.hip")
 HEADERS = ("bpm_common.h", "bpm_prof.h", "gemm_dma.h")
 ARCH = "gfx950"
 PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5, "xblock": 6}
@@ -175,6 +175,10 @@ SIGNATURES = {
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
+    "bpm_im2col1d": [_I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _P],
+    "bpm_col2im1d": [_P, _P, _I, _I, _I, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _I, _P],
+    "bpm_adaptive_pool1d_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "bpm_adaptive_pool1d_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "bpm_xblock_fwd": [_I, C.POINTER(XBlockProblem), _I, _U64, _P],
     "bpm_tail_fwd": [C.POINTER(TailDesc), _U64, _P],
     "bpm_tail_bwd": [C.POINTER(TailDesc), C.POINTER(TailGrads), _P],

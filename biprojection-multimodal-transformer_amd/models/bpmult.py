@@ -8,8 +8,9 @@ encoders, the dense Fusion-GMU layers, the time-axis maps, and the [B,d] tail
 (level 1->3 residual + token pick, final n-way GMU, residual head) -- runs as
 grouped HIP launches orchestrated by `_Trunk` behind ONE autograd node
 (`_ModelFn`): features in, (logits, gates) out.  The front-ends upstream of
-the path (text encoder, AudioEncoder, poster projection) are ordinary
-PyTorch-ROCm modules.
+the path: the text encoder is an ordinary PyTorch-ROCm module (HF BERT from a
+local directory); the AudioEncoder convolution stack and the poster projection
+run on this library's GEMM and row kernels (frontend.py).
 
 Deliberate departures from the reference's *behaviour as shipped* (all listed
 in SURVEY.md section 0): the 3-modal final GMU takes three inputs (the
@@ -74,17 +75,21 @@ class TextShiftingLayer(nn.Module):
 
 
 class AudioEncoder(nn.Module):
-    """Front-end of the 4-modal model (mmtr.py:93-108); upstream of the hot path."""
+    """Front-end of the 4-modal model (mmtr.py:93-108): Conv1d(96,96,128,stride 2) x 2 + AdaptiveAvgPool1d(200).  The
+    modules below only hold the parameters under the reference's names; `encode` runs the stack on the HIP path
+    (frontend.py: window gather + grouped MFMA GEMM + pooling kernels) and returns [B, 200, 96], i.e. the reference's
+    `audio_enc(audio).transpose(1, 2)`."""
 
     def __init__(self, args=None):
         super().__init__()
         self.conv_layers = nn.ModuleList([nn.Conv1d(96, 96, 128, stride=2), nn.Conv1d(96, 96, 128, stride=2),
                                           nn.AdaptiveAvgPool1d(200)])
 
-    def forward(self, x):
-        for layer in self.conv_layers:
-            x = layer(x)
-        return x
+    def encode(self, x, precision: str):
+        from ..frontend import audio_encoder_forward
+        pool = self.conv_layers[2].output_size
+        pool = pool[0] if isinstance(pool, (tuple, list)) else pool
+        return audio_encoder_forward(x, (self.conv_layers[0], self.conv_layers[1]), int(pool), precision)
 
 
 class BertEncoder(nn.Module):
@@ -713,7 +718,9 @@ class MultiprojectionMMTransformerGMUClf(_BPMulTBase):
         self._init_time_maps()
 
     def forward(self, txt, mask, segment, img, audio, poster, output_gate=False):
+        from ..frontend import skinny_linear
+        prec = self.precision or config.precision()
         x_l = self.enc(txt, mask, segment)
-        x_a = self.audio_enc(audio).transpose(1, 2)            # [B,96,A] -> [B,A,96]
-        logits, z = self._run(x_l, img, x_a, self.proj_poster(poster))
+        x_a = self.audio_enc.encode(audio, prec)               # [B,96,T_a] -> [B,A,96] (mmtr.py:449)
+        logits, z = self._run(x_l, img, x_a, skinny_linear(poster, self.proj_poster.weight, prec))
         return (logits, z) if output_gate else logits

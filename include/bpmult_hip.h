@@ -276,6 +276,19 @@ typedef struct bpm_xblock_problem {
 } bpm_xblock_problem;
 int bpm_xblock_fwd(int dtype, const bpm_xblock_problem* probs, int n, uint64_t seed, void* stream);
 
+/* Front-end: AudioEncoder of the 4-modal model (mmtr.py:93-108: Conv1d(96,96,k=128,stride 2) x 2 + AdaptiveAvgPool1d(200)).
+ * A convolution is computed as a product over window rows with bpm_gemm_grouped:
+ *   col[(b,l), ci*K + k] = x[b*sb + ci*sc + (stride*l + k)*sl]      (bpm_im2col1d; x fp32 with element strides, col CT [B*Lout, ldcol])
+ *   y[(b,l), co] = col . W[co, :]^T + bias                          (NT; weight gradient TN + colsum_a, data gradient NN)
+ *   dx[b, ci, p] = sum of the window entries that cover p           (bpm_col2im1d: gather, `accumulate` != 0 adds)
+ * bpm_adaptive_pool1d_*: torch.nn.AdaptiveAvgPool1d over the position axis of a fp32 [(b,l), C] matrix -> [(b,i), C]. */
+int bpm_im2col1d(int dtype, const float* x, void* col, int B, int Cin, int K, int stride, int Lin, int Lout,
+                 int64_t sb, int64_t sc, int64_t sl, int ldcol, void* stream);
+int bpm_col2im1d(const float* dcol, float* dx, int B, int Cin, int K, int stride, int Lin, int Lout,
+                 int64_t sb, int64_t sc, int64_t sl, int ldcol, int accumulate, void* stream);
+int bpm_adaptive_pool1d_fwd(const float* y, float* out, int B, int C, int Lin, int Lout, void* stream);
+int bpm_adaptive_pool1d_bwd(const float* dout, float* dy, int B, int C, int Lin, int Lout, void* stream);
+
 /* The [B,d]-sized tail (all fp32, exact f32 VALU arithmetic from the fp32 master weights):
  *   x_i   = (top_i + mid_i)[0] + (top_i + mid_i)[N_i - 1]            level 1 -> 3 residual + token pick, mmtr.py:806-808
  *           (i = l, v, a in the order of mmtr.py:857); x_3 = extra (poster projection, 4-modal, mmtr.py:574)

@@ -741,3 +741,36 @@ def test_fused_crossmodal_block_matches_separate_kernels(B, T, S, masked, pa, pr
         out_ref = o_rows.to(ct).double() @ Wo.double().T + bo.double() + resid.double()
         close(f["lse"], lse_ref, 2e-2, "lse vs fp64")
         close(f["out"], out_ref, 3e-2, "out vs fp64")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_audio_encoder_frontend_against_torch_and_reference_fixture(prec):
+    """AudioEncoder on the HIP path (window gather + grouped GEMM + adaptive pooling; mmtr.py:93-108) against
+    torch.nn.functional.conv1d / adaptive_avg_pool1d in fp64 with autograd (outputs, weight / bias / input gradients), and
+    against the reference's own output stored in the f8 fixture (`audio_feat`, [B, 96, 200])."""
+    import os
+    import numpy as np
+    from detgen import det, det_param
+    from bpmult_amd.models.bpmult import AudioEncoder
+    enc = AudioEncoder()
+    with torch.no_grad():
+        for k, p in enc.named_parameters():
+            p.copy_(torch.from_numpy(det_param("f8.audio_enc." + k, p.shape)))
+    aud = torch.from_numpy(det("f8.aud", (2, 96, 1000)))
+    ref_leaves = [p.detach().double().requires_grad_(True) for p in enc.parameters()]
+    w1, b1, w2, b2 = ref_leaves
+    xr = aud.double().requires_grad_(True)
+    yr = torch.nn.functional.adaptive_avg_pool1d(torch.nn.functional.conv1d(torch.nn.functional.conv1d(xr, w1, b1, stride=2), w2, b2, stride=2), 200)
+    wgt = torch.from_numpy(det("f8.audw", (2, 96, 200))).double()
+    (yr * wgt).sum().backward()
+    enc = enc.cuda()
+    x = aud.cuda().requires_grad_(True)
+    y = enc.encode(x, prec)                                   # [B, 200, 96]
+    (y * wgt.float().cuda().transpose(1, 2)).sum().backward()
+    t_out, t_g = (2e-5, 2e-4) if prec == "f32" else (2e-2, 4e-2)
+    close(y.transpose(1, 2), yr.detach(), t_out, "audio_feat vs torch")
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "f8_mmtrvapt.npz")))
+    close(y.transpose(1, 2), torch.from_numpy(g["audio_feat"]).double(), t_out, "audio_feat vs reference fixture")
+    close(x.grad, xr.grad, t_g, "d(audio)")
+    for (k, p), r in zip(enc.named_parameters(), ref_leaves):
+        close(p.grad, r.grad, t_g, "d(" + k + ")")
