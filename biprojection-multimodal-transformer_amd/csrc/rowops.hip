@@ -217,6 +217,7 @@ __global__ void embed_pos_bwd_kernel(const Grp<EmbP> grp, int d, float scale) {
 // per row, row held in registers (NE = ceil(span/64) elements per lane).
 // ---------------------------------------------------------------------------
 constexpr int MAXE = 32;
+constexpr int LN_WS_HEAD = 64;             // floats in front of the partial rows of a bpm_ln_bwd_ws workspace (ticket words)
 
 struct LnP {
     const float* x; const float* gamma; const float* beta; void* out; int ldo; int out_f32;
@@ -496,47 +497,67 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int 
         *(f32x4*)(&red[2][wv][4 * (lane + 64 * e)]) = ac[e];
     }
     __syncthreads();
-    // Per-block column sums.  With a workspace every block stores its three rows and ln_bwd_reduce_kernel adds them up
-    // (one owner per column, fixed order: bitwise reproducible).  Without one they go out as float atomics -- up to 128
-    // blocks per problem adding into the same three 3 KB rows, which runs an order of magnitude below the atomic rate
-    // (MI355X_MICROARCH, global float atomics, contention row) and was ~half of this kernel's time at hidden 768.
-    float* mine = ws ? ws + (size_t)blockIdx.x * 3 * d : nullptr;
+    // Per-block column sums.  With a workspace every block stores its three rows and the LAST block of the problem to
+    // finish adds them up (one owner per column, fixed order: bitwise reproducible) -- no second launch: a tiny dependent
+    // kernel behind this one waited ~45 us for CU slots beside the side stream's GEMMs.  Without a workspace they go out
+    // as float atomics -- up to 128 blocks per problem adding into the same three 3 KB rows, which runs an order of
+    // magnitude below the atomic rate (MI355X_MICROARCH, global float atomics, contention row).
+    // Hand-off (cdna_hip_programming.md Guideline 16 R1, counter form): partial rows stored write-through -> every wave's
+    // stores drained -> workgroup barrier -> ticket by one lane; the block that draws the last ticket acquires (agent
+    // scope: invalidates this CU's L1) and reads the other blocks' rows.  The ticket word is reset by its last
+    // user, so the workspace only has to be zero when it is created.
+    if (ws) {
+        __shared__ int s_last;
+        unsigned* cnt = (unsigned*)ws;                       // BPM_MAX_GROUP tickets, then the partial rows
+        float* rows = ws + LN_WS_HEAD;
+        // partial rows go out WRITE-THROUGH (sc1, 16 bytes per lane): no release fence is needed then -- an agent-scope
+        // release (buffer_wbl2) per block would write back the whole L2's dirty dx lines, measured +50 us per launch
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(rows + (size_t)blockIdx.x * 3 * d), 0, 3 * d * 4, 0x00020000);
+        for (int v = threadIdx.x; v < 3 * nch; v += NT) {
+            const int a = v / nch, c = 4 * (v - a * nch);
+            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) s4 += *(const f32x4*)(&red[a][w][c]);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4&)s4, rw, (a * d + c) * 4, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int pi = 0;                                          // (not &P - grp.p: taking that address sends the kernel arguments to scratch)
+#pragma unroll 1
+        for (int i = 1; i < grp.n; ++i)
+            if (blockIdx.x >= grp.blk0[i]) pi = i;
+        if (threadIdx.x == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(cnt + pi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = ticket == nblk - 1;
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(cnt + pi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // 3 d / 4 four-column slots (array a, columns 4 c4 ..), 16 partial rows in flight per thread
+        const float* first = rows + (size_t)grp.blk0[pi] * 3 * d;
+        const int nslot = 3 * nch;
+        for (int v = threadIdx.x; v < nslot; v += NT) {
+            const int a = v / nch, c4 = v - a * nch;
+            if ((a < 2 && !want_g) || (a == 2 && !want_c)) continue;
+            const float* src = first + a * d + 4 * c4;
+            f32x4 acc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+            for (unsigned b = 0; b < nblk; ++b) acc4 += *(const f32x4*)(src + (size_t)b * 3 * d);
+            float* dst = (a == 0 ? P.dgamma : a == 1 ? P.dbeta : P.csum) + 4 * c4;
+            *(f32x4*)dst = *(const f32x4*)dst + acc4;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < d; c += NT) {
         float sg = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; sc += red[2][w][c]; }
-        if (mine) { mine[c] = sg; mine[d + c] = sb; mine[2 * d + c] = sc; continue; }
         if (want_g) { atomicAdd(P.dgamma + c, sg); atomicAdd(P.dbeta + c, sb); }
         if (want_c) atomicAdd(P.csum + c, sc);
-    }
-}
-
-// second stage of the LayerNorm backward's parameter / bias gradients: column c of problem p = sum over that
-// problem's blocks, added (+=) into dgamma / dbeta / the cast column sums by a single owner.  Block = 64 columns x 4
-// row groups (each sums a quarter of the partial rows, 8 loads in flight), combined through LDS.
-__global__ __launch_bounds__(NT) void ln_bwd_reduce_kernel(const Grp<LnP> grp, int d, const float* __restrict__ ws, int cblk) {
-    __shared__ float part[3][4][64];
-    const int pi = blockIdx.x / cblk, col = threadIdx.x & 63, grp4 = threadIdx.x >> 6;
-    const int c = (blockIdx.x % cblk) * 64 + col;
-    const LnP& P = grp.p[pi];
-    const bool want_g = P.dgamma != nullptr, want_c = P.cast != nullptr && P.csum != nullptr;
-    if (!want_g && !want_c) return;                   // uniform per block
-    float sg = 0.f, sb = 0.f, sc = 0.f;
-    if (c < d) {
-#pragma unroll 8
-        for (unsigned b = grp.blk0[pi] + grp4; b < grp.blk0[pi + 1]; b += 4) {
-            const float* r = ws + (size_t)b * 3 * d;
-            sg += r[c]; sb += r[d + c]; sc += r[2 * d + c];
-        }
-    }
-    part[0][grp4][col] = sg; part[1][grp4][col] = sb; part[2][grp4][col] = sc;
-    __syncthreads();
-    if (grp4 == 0 && c < d) {
-        sg = (part[0][0][col] + part[0][1][col]) + (part[0][2][col] + part[0][3][col]);
-        sb = (part[1][0][col] + part[1][1][col]) + (part[1][2][col] + part[1][3][col]);
-        sc = (part[2][0][col] + part[2][1][col]) + (part[2][2][col] + part[2][3][col]);
-        if (want_g) { P.dgamma[c] += sg; P.dbeta[c] += sb; }
-        if (want_c) P.csum[c] += sc;
     }
 }
 
@@ -880,7 +901,7 @@ extern "C" int bpm_ln_fwd(int dtype, const bpm_ln_problem* q, int n, int d, floa
 }
 
 extern "C" size_t bpm_ln_bwd_ws_bytes(int n, int d) {
-    return (size_t)(n > 0 ? n : 0) * 128 * 3 * (size_t)(d > 0 ? d : 0) * sizeof(float);
+    return ((size_t)(n > 0 ? n : 0) * 128 * 3 * (size_t)(d > 0 ? d : 0) + LN_WS_HEAD) * sizeof(float);
 }
 
 extern "C" int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* q, int n, int d, uint64_t seed, void* ws, size_t ws_bytes, void* stream) {
@@ -898,10 +919,11 @@ extern "C" int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* q, int n, int d, u
         for (int i = 0; i < n; ++i) {
             if (q[i].cast && q[i].ldc > maxw) maxw = q[i].ldc;
             sums = sums || q[i].dgamma || (q[i].cast && q[i].cast_colsum);
+            if (((uintptr_t)q[i].dgamma | (uintptr_t)q[i].dbeta | (uintptr_t)q[i].cast_colsum) & 15) ws = nullptr;   // 16-byte row sums
         }
         float* w = nullptr;
         if (ws && sums) {
-            if (((uintptr_t)ws & 15) || ws_bytes < (size_t)g.blk0[n] * 3 * d * sizeof(float)) return BPM_ERR_ARG;
+            if (((uintptr_t)ws & 15) || ws_bytes < ((size_t)g.blk0[n] * 3 * d + LN_WS_HEAD) * sizeof(float)) return BPM_ERR_ARG;
             w = (float*)ws;
         }
 #define BPM_LN_BWDV(NV)                                                                                        \
@@ -909,11 +931,6 @@ extern "C" int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* q, int n, int d, u
             if (dtype == BPM_BF16) hipLaunchKernelGGL((ln_bwd_vec_kernel<bf16_t, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, w); \
             else hipLaunchKernelGGL((ln_bwd_vec_kernel<float, NV>), dim3(g.blk0[n]), dim3(NT), 0, s, g, d, w);                   \
             BPM_CHECK_LAUNCH();                                                                                \
-            if (w) {                                                                                           \
-                const int cblk = (d + 63) / 64;                                                                \
-                hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(n * cblk), dim3(NT), 0, s, g, d, w, cblk);       \
-                BPM_CHECK_LAUNCH();                                                                            \
-            }                                                                                                  \
             return 0;                                                                                          \
         }
         BPM_LN_BWDV(1) BPM_LN_BWDV(2) BPM_LN_BWDV(3) BPM_LN_BWDV(4)

@@ -99,7 +99,7 @@ __global__ void tail_combine_kernel(const float* __restrict__ z, const float* __
     h[idx] = v;
 }
 
-// data gradient: out[b, k] (+)= sum_j dy[b, j] W[j, k]  (* gate)  (+ add[b, k]);  block = 64 columns x 4 j-groups
+// data gradient: out[b, k] (+)= sum_j dy[b, j] W[j, k]  (* gate)  (+ add[b, k]);  block = 64 columns x 16 j-groups
 struct NnP {
     const float* dy; int lddy; const float* W; int ldw; int J, K;
     float* out; int ldo; int accumulate;
@@ -108,8 +108,9 @@ struct NnP {
     int blk0;
 };
 struct NnGrp { int n, B, total_blk; NnP p[8]; };
-__global__ __launch_bounds__(TNT) void tail_nn_kernel(const NnGrp g) {
-    __shared__ float part[3][BC][64];
+constexpr int NN_JG = 16;                  // j groups per block (1024 threads = 64 columns x 16 groups)
+__global__ __launch_bounds__(64 * NN_JG) void tail_nn_kernel(const NnGrp g) {
+    __shared__ float part[NN_JG - 1][BC][64];
     int bid = blockIdx.x, pi = 0;
 #pragma unroll 1
     for (int i = 1; i < g.n; ++i)
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(TNT) void tail_nn_kernel(const NnGrp g) {
 #pragma unroll
         for (int r = 0; r < BC; ++r) acc[r] = 0.f;
         if (kok) {
-            for (int j = jg; j < P.J; j += 4) {
+#pragma unroll 4
+            for (int j = jg; j < P.J; j += NN_JG) {
                 const float wv = P.W[(size_t)j * P.ldw + k];
 #pragma unroll
                 for (int r = 0; r < BC; ++r) acc[r] = fmaf(P.dy[(size_t)min(b0 + r, g.B - 1) * P.lddy + j], wv, acc[r]);
@@ -141,7 +143,9 @@ __global__ __launch_bounds__(TNT) void tail_nn_kernel(const NnGrp g) {
             for (int r = 0; r < BC; ++r) {
                 const int b = b0 + r;
                 if (b >= g.B) break;
-                float v = (acc[r] + part[0][r][col]) + (part[1][r][col] + part[2][r][col]);
+                float v = acc[r];
+#pragma unroll
+                for (int q = 0; q < NN_JG - 1; ++q) v += part[q][r][col];
                 if (P.gate) v = P.gate[(size_t)b * P.ldg + k] > 0.f ? v * P.gate_scale : 0.f;
                 if (P.add) v += P.add[(size_t)b * P.lda + k];
                 float* o = P.out + (size_t)b * P.ldo + k;
@@ -248,7 +252,7 @@ int launch_nn(NnGrp& g, hipStream_t s) {
     int blk = 0;
     for (int i = 0; i < g.n; ++i) { g.p[i].blk0 = blk; blk += (g.p[i].K + 63) / 64; }
     g.total_blk = blk;
-    hipLaunchKernelGGL(tail_nn_kernel, dim3(blk), dim3(TNT), 0, s, g);
+    hipLaunchKernelGGL(tail_nn_kernel, dim3(blk), dim3(64 * NN_JG), 0, s, g);
     BPM_CHECK_LAUNCH();
     return 0;
 }

@@ -228,7 +228,7 @@ def _ln_workspace(n: int, d: int, device) -> torch.Tensor:
     need = _lib.lib().bpm_ln_bwd_ws_bytes(n, d)
     t = _LN_WS.get(key)
     if t is None or t.numel() * 4 < need:
-        t = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+        t = torch.zeros((need + 3) // 4, device=device, dtype=torch.float32)      # ticket words must start at zero
         _LN_WS[key] = t
     return t
 

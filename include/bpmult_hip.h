@@ -222,8 +222,9 @@ typedef struct bpm_ln_problem {
 int bpm_ln_fwd(int dtype, const bpm_ln_problem* probs, int n, int d, float eps, void* stream);
 int bpm_ln_bwd(int dtype, const bpm_ln_problem* probs, int n, int d, uint64_t seed, void* stream);
 /* Same with a caller-provided workspace of at least bpm_ln_bwd_ws_bytes(n, d) bytes (16-byte aligned, private to the
- * stream): dgamma / dbeta / cast_colsum are then produced by per-block partial rows and a second, single-owner pass
- * (bitwise reproducible) instead of float atomics from every block into the same rows.  ws == NULL: as bpm_ln_bwd. */
+ * stream, ZERO when first used -- the library leaves its ticket words zero again): dgamma / dbeta / cast_colsum are then
+ * produced from per-block partial rows by the last block of each problem to finish (single owner per column, fixed
+ * order: bitwise reproducible) instead of float atomics from every block into the same rows.  ws == NULL: as bpm_ln_bwd. */
 size_t bpm_ln_bwd_ws_bytes(int n, int d);
 int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* probs, int n, int d, uint64_t seed, void* ws, size_t ws_bytes, void* stream);
 
