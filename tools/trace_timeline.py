@@ -14,7 +14,7 @@ def short(name):
     m = re.search(r"(gemm_tiled_kernel|gemm_dma_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|ln_fwd_kernel|"
                   r"ln_bwd_kernel|ln_fwd_vec_kernel|ln_bwd_vec_kernel|rows_cast_kernel|colsum_kernel|fold_bias_kernel|"
                   r"unfold_grads_kernel|embed_pos_fwd_kernel|embed_pos_bwd_kernel|pack_rows_\w+_kernel|gmu2_\w+_kernel|"
-                  r"pack_weights_kernel)", name)
+                  r"pack_weights_kernel|xblock_fwd_kernel|tail_\w+_kernel|im2col1d_kernel|col2im1d_kernel|pool_\w+_kernel|adam_kernel)", name)
     if m:
         k = m.group(1)
         if k in ("gemm_tiled_kernel", "gemm_dma_kernel"):      # needs mangled names (rocprofv3 -M): the demangler garbles __bf16 templates
