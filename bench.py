@@ -263,9 +263,12 @@ def main():
     secondary = world == 1 and not a.no_secondary and not a.batch
     torch.manual_seed(1234 + rank)
     model = get_model(model_args(c, a.precision)).to(dev).train()
-    if world > 1:                                     # same replica everywhere
-        for p in model.parameters():
-            dist.broadcast(p.data, 0)
+    if world > 1:                                     # same replica everywhere: the flat trunk master in one message, the tail per tensor
+        st = model._ensure_store()
+        dist.broadcast(st.master, 0)
+        for n, p in model.named_parameters():
+            if n not in st.params:
+                dist.broadcast(p.data, 0)
     opt = FusedAdam(model, lr=1e-3)          # one kernel over the flat trunk buffers (reported as optimizer_ms, not timed)
     sync = GradSync(model, optimizer=opt, compress=a.grad_compress)   # 1/world is folded into the optimizer's grad_scale
     batch = synth_batch(c, B, 1234 + rank, dev)

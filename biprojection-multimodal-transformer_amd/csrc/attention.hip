@@ -54,6 +54,18 @@ constexpr int KT = 64;      // keys per tile (forward / dQ)
 #define BPM_ATTN_QT 64
 #endif
 constexpr int QT = BPM_ATTN_QT;      // queries per tile (dK/dV): a multiple of 32
+
+// Waves per SIMD each kernel is compiled for (register budget 512 / waves), per kernel (0 forward, 1 dQ, 2 dK/dV),
+// compute type and padded head_dim: the largest occupancy at which the kernel does not spill.  At head_dim 64 (hidden
+// 768 / 12 heads) the bf16 dK/dV kernel spilled 128 bytes per lane at 4 waves; at 3 (166 registers) the backward pass of
+// the headline workload went 457 -> 346 us per launch.  The f32 (parity-mode) kernels need one wave fewer throughout.
+template <typename CT>
+constexpr int attn_waves(int kernel, int dhp) {
+    const bool bf = sizeof(CT) == 2;
+    if (dhp <= 32) return kernel == 0 ? BPM_ATTN_WF : (kernel == 2 && !bf ? 3 : 4);
+    if (dhp <= 64) return kernel == 0 ? (bf ? 4 : 3) : kernel == 1 ? (bf ? 4 : 3) : (bf ? 3 : 2);
+    return kernel == 0 ? (bf ? 3 : 2) : BPM_ATTN_W128;
+}
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct AProb {
@@ -152,7 +164,7 @@ BPM_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_ex
 // forward
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 32 ? BPM_ATTN_WF : (DHP <= 64 ? 4 : (sizeof(CT) == 2 ? 3 : 2)), DHP <= 32 ? BPM_ATTN_WF : (DHP <= 64 ? 4 : (sizeof(CT) == 2 ? 3 : 2))))) void attn_fwd_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(0, DHP), attn_waves<CT>(0, DHP)))) void attn_fwd_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
 // backward, dQ (and delta = rowsum(dO * O))
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 64 ? 4 : BPM_ATTN_W128, DHP <= 64 ? 4 : BPM_ATTN_W128))) void attn_bwd_dq_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(1, DHP), attn_waves<CT>(1, DHP)))) void attn_bwd_dq_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <=
 // backward, dK and dV
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(DHP <= 64 ? 4 : BPM_ATTN_W128, DHP <= 64 ? 4 : BPM_ATTN_W128))) void attn_bwd_dkv_kernel(const AGroup grp) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(2, DHP), attn_waves<CT>(2, DHP)))) void attn_bwd_dkv_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * QT * C::STRIDE + 2 * QT * 4];
