@@ -276,44 +276,52 @@ BPM_DEV EpiRow epi_row(const Prob& P, int m) {
 // Interleaving them per tile (load, compute, store, load, ...) serialises one memory round trip per tile, because
 // the loads may alias the stores and cannot be hoisted by the compiler: measured 6.6 us of a 16 us workgroup.
 template <typename CT, int NB>
-BPM_DEV void epilogue_fast(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NB], f32x4& csum) {
-    // rows mrow + 16*b: their offsets are recomputed where needed (a few multiplies) instead of living in a 24-register
-    // table through the whole epilogue -- the table was what pushed the kernel past the 4 -> 5 waves/SIMD budget
-    const bool colok = nb < P.N;                        // N % 4 == 0: a lane's 4 columns are all in or all out
-    const uint32_t nbc = colok ? (uint32_t)nb : 0u;     // clamped column for the loads
-    const bool f32out = P.out_kind == BPM_OUT_F32;
-    const bool accum = f32out && (P.flags & BPM_GEMM_ACCUM);
+struct EpiSide {                                        // side operands of NB tiles, loaded ahead of the arithmetic
     typedef typename std::conditional<sizeof(CT) == 4, f32x4, bf16x4>::type gate_t;
-
-    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bias;
     f32x4 addv[NB];
     gate_t gt[NB];
-    if (P.bias_n) bias = *(const f32x4*)(P.bias_n + nbc);
+};
+
+template <typename CT, int NB>
+BPM_DEV void epi_fast_load(const Prob& P, int mrow, int nb, EpiSide<CT, NB>& s) {
+    // rows mrow + 16*b: their offsets are recomputed where needed (a few multiplies) instead of living in a 24-register
+    // table through the whole epilogue -- the table was what pushed the kernel past the 4 -> 5 waves/SIMD budget
+    typedef typename EpiSide<CT, NB>::gate_t gate_t;
+    const uint32_t nbc = nb < P.N ? (uint32_t)nb : 0u;  // clamped column for the loads
+    const bool accum = P.out_kind == BPM_OUT_F32 && (P.flags & BPM_GEMM_ACCUM);
+    s.bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (P.bias_n) s.bias = *(const f32x4*)(P.bias_n + nbc);
     if (P.gate) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) gt[b] = *(const gate_t*)((const CT*)P.gate + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldg + nbc);
+        for (int b = 0; b < NB; ++b) s.gt[b] = *(const gate_t*)((const CT*)P.gate + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldg + nbc);
     } else {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) gt[b] = gate_t{};
+        for (int b = 0; b < NB; ++b) s.gt[b] = gate_t{};
     }
     if (P.resid) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)(P.resid + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldr + nbc);
+        for (int b = 0; b < NB; ++b) s.addv[b] = *(const f32x4*)(P.resid + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldr + nbc);
     } else if (accum) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) addv[b] = *(const f32x4*)((const float*)P.C + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldc + nbc);
+        for (int b = 0; b < NB; ++b) s.addv[b] = *(const f32x4*)((const float*)P.C + (uint32_t)min(mrow + 16 * b, P.M - 1) * (uint32_t)P.ldc + nbc);
     } else {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) addv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) s.addv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
 
+template <typename CT, int NB>
+BPM_DEV void epi_fast_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NB], const EpiSide<CT, NB>& s, f32x4& csum) {
+    const bool colok = nb < P.N;                        // N % 4 == 0: a lane's 4 columns are all in or all out
+    const bool f32out = P.out_kind == BPM_OUT_F32;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const EpiRow e = epi_row(P, mrow + 16 * b);
         const bool valid = e.ok && colok;
         f32x4 x = acc[b];
         if (valid) {
-            x += bias;
+            x += s.bias;
             if (P.alpha != 1.f) x *= P.alpha;
             if (P.flags & BPM_GEMM_RELU) {
 #pragma unroll
@@ -321,7 +329,7 @@ BPM_DEV void epilogue_fast(const Prob& P, int mrow, int nb, const f32x4 (&acc)[N
             }
             if (P.gate) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = (float)gt[b][q] > 0.f ? x[q] * P.gate_scale : 0.f;
+                for (int q = 0; q < 4; ++q) x[q] = (float)s.gt[b][q] > 0.f ? x[q] * P.gate_scale : 0.f;
             }
             if (P.drop.thresh != 0) {                   // m*N + nb is even: two hash pairs
                 float d0, d1, d2, d3;
@@ -330,7 +338,7 @@ BPM_DEV void epilogue_fast(const Prob& P, int mrow, int nb, const f32x4 (&acc)[N
                 x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
             }
             csum += x;
-            x += addv[b];
+            x += s.addv[b];
         }
         if (f32out) {
             if (valid) *(f32x4*)((float*)P.C + e.offc + nb) = x;
@@ -344,13 +352,25 @@ BPM_DEV void epilogue_fast(const Prob& P, int mrow, int nb, const f32x4 (&acc)[N
             uint32_t h = (uint32_t)nb / (uint32_t)P.hdh, c = (uint32_t)nb - h * (uint32_t)P.hdh;
             const uint32_t hstride = (uint32_t)(P.hT * P.hdhp);
             CT* base = (CT*)P.C + e.hrow;
+            if (sizeof(CT) == 2 && (P.hdh & 3) == 0) {  // the 4 columns stay inside one head
+                bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3];
+                *(bf16x4*)((bf16_t*)base + h * hstride + c) = o;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                base[h * hstride + c] = Tr<CT>::from_f(x[q]);
-                if (++c == (uint32_t)P.hdh) { c = 0; ++h; }
+                for (int q = 0; q < 4; ++q) {
+                    base[h * hstride + c] = Tr<CT>::from_f(x[q]);
+                    if (++c == (uint32_t)P.hdh) { c = 0; ++h; }
+                }
             }
         }
     }
+}
+
+template <typename CT, int NB>
+BPM_DEV void epilogue_fast(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NB], f32x4& csum) {
+    EpiSide<CT, NB> s;
+    epi_fast_load<CT, NB>(P, mrow, nb, s);
+    epi_fast_apply<CT, NB>(P, mrow, nb, acc, s, csum);
 }
 
 // one wave's column block: rows (m0 + 16*b + r), b < NB, columns nb..nb+3
@@ -746,7 +766,14 @@ int launch_dma_cfg(int variant, const Group& g, hipStream_t s) {
     switch (variant) {
         case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_dma_kernel<true, true, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
         case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_dma_kernel<true, false, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
-        case BPM_GEMM_TN: hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
+        case BPM_GEMM_TN:
+            if constexpr ((16 * TMW * WMD) % 128 == 0) {
+                bool xs = false;
+                for (int i = 0; i < g.nprob; ++i) xs = xs || g.p[i].colsum_x != nullptr;
+                if (xs) hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, true>), grid, block, 0, s, g);
+                else hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, false>), grid, block, 0, s, g);
+            } else return BPM_ERR_ARG;         // k-strided X: 128-column sub-images only
+            break;
         default: return BPM_ERR_ARG;
     }
     BPM_CHECK_LAUNCH();
@@ -754,7 +781,8 @@ int launch_dma_cfg(int variant, const Group& g, hipStream_t s) {
 }
 
 struct DmaCfg { int bm, bn; };
-constexpr DmaCfg DMA_CFGS[] = {{128, 128}, {256, 128}, {256, 256}, {256, 256}, {128, 128}};
+constexpr DmaCfg DMA_CFGS[] = {{128, 128}, {256, 128}, {256, 256}, {256, 256}, {128, 128}, {320, 256}};
+constexpr int CFG_TALL = 5;               // 320-row tiles (k-contiguous X only): see the tile choice in bpm_gemm_grouped
 constexpr int N_DMA_CFGS = sizeof(DMA_CFGS) / sizeof(DMA_CFGS[0]);
 
 int launch_dma(int cfg, int variant, const Group& g, hipStream_t s) {
@@ -764,8 +792,20 @@ int launch_dma(int cfg, int variant, const Group& g, hipStream_t s) {
         case 2: return launch_dma_cfg<2, 4, 8, 2>(variant, g, s);      // 256 x 256,  8 waves of 128 x 64
         case 3: return launch_dma_cfg<4, 4, 4, 2>(variant, g, s);      // 256 x 256, 16 waves of 64 x 64
         case 4: return launch_dma_cfg<2, 2, 4, 3>(variant, g, s);      // 128 x 128,  3 stages
+        case CFG_TALL: return launch_dma_cfg<2, 4, 10, 2>(variant, g, s);   // 320 x 256, 8 waves of 160 x 64 (NT / NN)
     }
     return BPM_ERR_ARG;
+}
+
+int num_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return ncu;
 }
 
 // tuning hook (tools/gemm_lab.py): -1 = automatic choice, -2 = never the LDS-DMA kernel, 0.. = force DMA_CFGS[i] where legal
@@ -824,8 +864,26 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
             big = big && q.M >= 256 && q.N >= 256 && q.K >= 256 && (variant != BPM_GEMM_TN || tm * tn >= 24) &&
                   (double)q.M * q.N >= 0.8 * (double)(tm * 256) * (double)(tn * 256);
         }
-        if (legal && g_force_dma >= 0) dma = g_force_dma;
-        else if (legal && big) dma = variant == BPM_GEMM_TN ? 2 : 3;
+        if (legal && g_force_dma >= 0) dma = g_force_dma == CFG_TALL && variant == BPM_GEMM_TN ? -1 : g_force_dma;
+        else if (legal && big) {
+            dma = variant == BPM_GEMM_TN ? 2 : 3;
+            if (variant != BPM_GEMM_TN) {
+                // One workgroup per CU: a launch takes ceil(tiles / CUs) rounds of one tile each, and at the model's
+                // shapes the tile count sits just above a multiple of the CU count (six problems of 4096 x 768 are 288
+                // tiles of 256 x 256: a second round for 32 of them).  320-row tiles (13 instead of 16 per 4096 rows: 234
+                // tiles, one round of 1.25x the work) win whenever they save a round; per flop the 16-wave 256-row
+                // kernel is ~5 % faster.
+                const long ncu = num_cus();
+                long t256 = 0, t320 = 0;
+                for (int i = 0; i < nprob; ++i) {
+                    const long tn = (probs[i].N + 255) / 256;
+                    t256 += (probs[i].M + 255) / 256 * tn;
+                    t320 += (probs[i].M + 319) / 320 * tn;
+                }
+                const long r256 = (t256 + ncu - 1) / ncu, r320 = (t320 + ncu - 1) / ncu;
+                if (r320 * 320 * 21 < r256 * 256 * 20) dma = CFG_TALL;
+            }
+        }
     }
     // under-filled weight-gradient launches (fewer than two 128-row workgroups per CU) run 64-row workgroups:
     // measured 98 -> 77 us for the 24 attention weight gradients of a layer (360 -> 600 workgroups)

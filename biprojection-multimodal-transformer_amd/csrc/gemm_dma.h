@@ -149,7 +149,7 @@ struct DmaSide {
     static constexpr int IMG_BYTES = ROWS * DROW;                 // both layouts: ROWS * 64 k * 2 B
     static constexpr int PIECES = IMG_BYTES / 1024;
     static constexpr int PER_WAVE = PIECES / NW;
-    static_assert(PIECES % NW == 0 && ROWS % 128 == 0, "pieces divide over the waves");
+    static_assert(PIECES % NW == 0 && (KCONTIG || ROWS % 128 == 0), "pieces divide over the waves; k-strided images are 128-column sub-images");
     static_assert(NW == 4 || NW == 8 || NW == 16, "piece -> swizzle mapping assumes 4, 8 or 16 waves");
 
     // Wave w moves pieces w, w + NW, ...  The per-lane byte offset of its piece 0 -- the other pieces differ by a
@@ -217,15 +217,18 @@ BPM_DEV void dma_issue_part(__amdgpu_buffer_rsrc_t rsx, __amdgpu_buffer_rsrc_t r
 }
 
 // WMD x WND waves, each a (16 TMW) x 64 block of the (16 TMW WMD) x (64 WND) workgroup tile; NS LDS stages.
-template <bool XK, bool YK, int WMD, int WND, int TMW, int NS>
+// XS: some problem of the launch wants the column sums of X (bias gradient beside a weight gradient, TN only); without
+// them the 8 / 4 extra accumulators are not carried (they spilled the 128 x 64 wave tile past its 256 registers).
+template <bool XK, bool YK, int WMD, int WND, int TMW, int NS, bool XS = false>
 __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group grp) {
+    static_assert(!XS || (!XK && !YK), "column sums of X belong to the weight-gradient product");
     constexpr int NW = WMD * WND, BMD = 16 * TMW * WMD, BND = 64 * WND, WROWS = 16 * TMW;
     typedef DmaSide<XK, BMD, NW> SX;
     typedef DmaSide<YK, BND, NW> SY;
     constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
     constexpr int LPS = SX::PER_WAVE + SY::PER_WAVE;          // DMA instructions per wave and stage
     static_assert(NS == 2 || NS == 3, "2 or 3 stages");
-    static_assert(TMW == 4 || TMW == 8, "wave tile 64 x 64 or 128 x 64");
+    static_assert(TMW == 4 || TMW == 8 || TMW == 10, "wave tile 64 x 64, 128 x 64 or 160 x 64");
     __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
         for (int b = 0; b < TMW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] f32x4 xs[TMW];
     [[maybe_unused]] bool do_xs = false;
-    if constexpr (!XK && !YK) {            // bias gradient beside a weight gradient: column sums of X (see the tiled kernel)
+    if constexpr (XS) {                    // bias gradient beside a weight gradient: column sums of X (see the tiled kernel)
         do_xs = P.colsum_x != nullptr && n0 == 0 && wn == 0;
 #pragma unroll
         for (int b = 0; b < TMW; ++b) xs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
             for (int b = 0; b < TMW; ++b) fx[b] = SX::frag(ix, wm * WROWS + 16 * b, ks, lane);
 #pragma unroll
             for (int a = 0; a < 4; ++a) fy[a] = SY::frag(iy, wn * 64 + 16 * a, ks, lane);
-            if constexpr (!XK && !YK) {
+            if constexpr (XS) {
                 if (do_xs) {
                     bf16x8 one;
 #pragma unroll
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
 
     const int r = lane & 15, g = lane >> 4;
     const int mw = m0 + wm * WROWS;
-    if constexpr (!XK && !YK) {
+    if constexpr (XS) {
         if (do_xs && g == 0) {
 #pragma unroll
             for (int b = 0; b < TMW; ++b) {
@@ -366,5 +369,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     };
     pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{});
     pass(std::integral_constant<int, 2>{}); pass(std::integral_constant<int, 3>{});
+    pass(std::integral_constant<int, 4>{});
+    static_assert(TMW <= 10, "passes unrolled for up to 160 rows per wave");
     if (P.colsum) flush_colsum_wide(P, cs, nbw, lane);
 }

@@ -91,6 +91,7 @@ class ParamStore:
 
     def __init__(self, named_params: Sequence[Tuple[str, torch.nn.Parameter]], dtype: int):
         self.dtype = dtype
+        self.side_low = True                            # side-stream priority: set by the plan that launches over this store
         self.names = [n for n, _ in named_params]
         self.params = {n: p for n, p in named_params}
         dev = named_params[0][1].device
@@ -155,7 +156,7 @@ class ParamStore:
         self._prezero_ev = None
         if self._fresh() and _SIDE:
             main = torch.cuda.current_stream()
-            side = _side_stream(main.device)
+            side = _side_stream(main.device, 1, self.side_low)
             side.wait_stream(main)                      # the previous step's consumers of gflat (optimizer, all-reduce)
             with torch.cuda.stream(side):
                 self.gflat.zero_()
@@ -312,20 +313,25 @@ _SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
 # dK / dV feed only side-stream work (weight gradients, key/value dgrad).  At hidden 300 the side stream is the longer
 # one and moving the pass there costs 1 ms/step; at hidden 768 the main stream is (41 ms against 23) and it saves ~4.
 _DKV_SIDE_ENV = os.environ.get("BPMULT_DKV_SIDE", "auto")
-_side_streams: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
+_side_streams: Dict[Tuple[int, int, bool], "torch.cuda.Stream"] = {}
+# Priority of the side stream: "low" (the dispatcher fills CUs from the main stream first), "normal", or "auto": low
+# below hidden 512, normal from there on.  Measured on MI355X: at hidden 300 low wins (16.9 -> 16.6 ms/step); at hidden
+# 768 every GEMM workgroup owns a CU for 50-300 us, the side stream's weight gradients are a third of the step's work,
+# and starving them only lengthens the tail (37.97 ms/step low, 37.53 normal).
+_SIDE_PRIORITY_ENV = os.environ.get("BPMULT_SIDE_PRIORITY", "auto")
 
 
-def _side_stream(device, which: int = 1) -> "torch.cuda.Stream":
-    """One side stream per device, created through the C ABI at the device's LOWEST priority (the dispatcher
-    then fills CUs from the main stream first); BPMULT_SIDE_PRIORITY=normal keeps the default priority."""
+def _side_stream(device, which: int = 1, low: bool = True) -> "torch.cuda.Stream":
+    """Side streams per device, created through the C ABI (low: at the device's LOWEST priority)."""
     dev_i = device.index if device.index is not None else torch.cuda.current_device()
-    key = (dev_i, which)
+    if _SIDE_PRIORITY_ENV in ("low", "normal"):
+        low = _SIDE_PRIORITY_ENV == "low"
+    key = (dev_i, which, bool(low))
     if key not in _side_streams:
         from . import _lib
-        low = os.environ.get("BPMULT_SIDE_PRIORITY", "low") != "normal"
         out = C.c_void_p()
         with torch.cuda.device(dev_i):
-            _lib.check(_lib.lib().bpm_stream_create(int(low), C.byref(out)), "bpm_stream_create")
+            _lib.check(_lib.lib().bpm_stream_create(int(bool(low)), C.byref(out)), "bpm_stream_create")
         _side_streams[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", dev_i))
     return _side_streams[key]
 
@@ -430,6 +436,8 @@ class EncoderGroupPlan:
                 ud.append(u)
             self._unfold.append((ops.device_table(ud), len(ud), blk))
         self._dkv_side = _DKV_SIDE_ENV if _DKV_SIDE_ENV != "auto" else ("1" if d >= 512 else "0")
+        self._side_low = d < 512
+        self.store.side_low = self._side_low
         self.fused_block = (FUSE_SHORT_BLOCKS and self.dtype == BPM_BF16 and self.dh == 128 and self.ld == d
                             and all(e.T <= 64 and e.S <= 64 and e.T_full is None for e in self.encs))
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
@@ -590,7 +598,7 @@ class EncoderGroupPlan:
                 self._exec(s[1] if s[0] in (SIDE, SIDE2) else s, seed)
             return
         main = torch.cuda.current_stream()
-        side = _side_stream(main.device)
+        side = _side_stream(main.device, 1, self._side_low)
         marks: Dict[int, torch.cuda.Event] = {}
         main_dirty, side_dirty = True, False
         for s in steps:
@@ -601,7 +609,7 @@ class EncoderGroupPlan:
                     main.wait_event(ev)
                     side_dirty = False
             elif s[0] is SIDE2:                     # third stream: starts right behind the main stream's last launch
-                side2 = _side_stream(main.device, 2)
+                side2 = _side_stream(main.device, 2, self._side_low)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side2.wait_event(ev)

@@ -116,6 +116,34 @@ def test_gemm_large_tile_paths_bf16(variant, M, N, K):
             close(cs, Ar.double().sum(0), 1e-4 if dtype == BPM_F32 else 2e-3, "colsum_a")
 
 
+@pytest.mark.parametrize("variant,M,N,K", [(GEMM_NT, 1000, 520, 328), (GEMM_NN, 1000, 520, 328), (GEMM_NT, 1300, 768, 768), (GEMM_NN, 960, 1024, 3072)])
+def test_gemm_tall_tile_ragged(variant, M, N, K):
+    """The 320 x 256 configuration (picked when it saves a round of workgroups: gemm.hip, tile choice) forced on ragged
+    shapes -- rows past M in the last 320-row tile, a k tail, a column tail -- against fp64 on the bf16-rounded operands."""
+    import ctypes as C
+    from bpmult_amd import _lib
+    L = _lib.lib()
+    L.bpm_debug_gemm_force.argtypes = [C.c_int]
+    pad64 = lambda n: (n + 63) // 64 * 64
+    A, Ar = to_ct(rnd(M, K, seed=21), BPM_BF16, pad64(K))
+    if variant == GEMM_NT:
+        Bm, Br = to_ct(rnd(N, K, seed=22, scale=K ** -0.5), BPM_BF16, pad64(K))
+        ref = Ar.double() @ Br.double().T
+    else:
+        Bm, Br = to_ct(rnd(K, N, seed=22, scale=K ** -0.5), BPM_BF16)
+        ref = Ar.double() @ Br.double()
+    bias, resid = rnd(N, seed=23).to(DEV), rnd(M, N, seed=24).to(DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    p = ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N, bias_n=bias, resid=resid, ldr=N, flags=ops.F_KPAD)
+    try:
+        _lib.check(L.bpm_debug_gemm_force(5), "force")
+        ops.gemm_grouped(BPM_BF16, variant, [p, p, p])
+        torch.cuda.synchronize()
+    finally:
+        L.bpm_debug_gemm_force(-1)
+    close(out, ref + bias.cpu().double() + resid.cpu().double(), 2e-3, f"tall tile v{variant}")
+
+
 def test_gemm_large_tile_epilogues_match_small_tile():
     """Every fused epilogue through the LDS-DMA kernel (wide LDS-transposed stores) against the 128 x 64 kernel on the
     same operands: relu + dropout -> CT, gate + column sums -> CT, head-major scatter (head_dim 128 and 64), += into f32.
@@ -133,7 +161,7 @@ def test_gemm_large_tile_epilogues_match_small_tile():
     base = rnd(M, N, seed=15).to(DEV)
     res = {}
     try:
-        for cfg in (-2, 3, 2, 0):
+        for cfg in (-2, 3, 2, 0, 5):
             _lib.check(L.bpm_debug_gemm_force(cfg), "force")
             o1 = torch.full((M, N), float("nan"), device=DEV).to(ctt)
             o2 = torch.full((M, N), float("nan"), device=DEV).to(ctt)
@@ -151,7 +179,7 @@ def test_gemm_large_tile_epilogues_match_small_tile():
             res[cfg] = [t.float().cpu() for t in (o1, o2, o3, o4, o5, cs)]
     finally:
         L.bpm_debug_gemm_force(-1)
-    for cfg in (3, 2, 0):
+    for cfg in (3, 2, 0, 5):
         for i, nm in enumerate(("relu+drop CT", "gate CT", "heads 128", "heads 64", "accum f32", "colsum")):
             close(res[cfg][i], res[-2][i], 1e-2 if i < 4 else 2e-4, f"cfg {cfg} {nm}")
         assert ((res[cfg][0] == 0) == (res[-2][0] == 0)).all(), "dropout / relu zero pattern must be identical"

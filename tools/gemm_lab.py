@@ -21,8 +21,8 @@ from bpmult_amd.ops import (BPM_BF16, F_ACCUM, F_KPAD, F_RELU, GEMM_NN, GEMM_NT,
 
 DEV = "cuda"
 CT = torch.bfloat16
-NCFG = 5
-NAMES = {-2: "tiled", 0: "128x128 4w", 1: "256x128 8w", 2: "256x256 8w", 3: "256x256 16w", 4: "128x128 ns3"}
+NCFG = 6
+NAMES = {-1: "auto", -2: "tiled", 0: "128x128 4w", 1: "256x128 8w", 2: "256x256 8w", 3: "256x256 16w", 4: "128x128 ns3", 5: "320x256 8w"}
 
 
 def force(cfg):
@@ -43,7 +43,8 @@ def rc(r, c, ld, scale=1.0):
 
 def check():
     bad = 0
-    shapes = [(256, 256, 256), (300, 260, 320), (4096, 768, 768), (777, 1000, 1000), (512, 384, 192), (1600, 768, 3072)]
+    shapes = [(256, 256, 256), (300, 260, 320), (4096, 768, 768), (777, 1000, 1000), (512, 384, 192), (1600, 768, 3072),
+              (8192, 2304, 640), (8000, 2052, 1500)]
     for variant, vn in ((GEMM_NT, "NT"), (GEMM_NN, "NN"), (GEMM_TN, "TN")):
         for (M, N, K) in shapes:
             if variant == GEMM_NT:
@@ -86,7 +87,7 @@ def check():
     gate = rc(M, N, N)
     bias = torch.randn(N, device=DEV)
     res = {}
-    for cfg in (-2, 0, 2, 3):
+    for cfg in (-2, 0, 2, 3, 5):
         force(cfg)
         o1 = torch.full((M, N), float("nan"), device=DEV).to(CT)
         o2 = torch.full((M, N), float("nan"), device=DEV).to(CT)
@@ -98,7 +99,7 @@ def check():
         ops.gemm_grouped(BPM_BF16, GEMM_NT, [p1, p2, p3], seed=77)
         torch.cuda.synchronize()
         res[cfg] = (o1.float(), o2.float(), o3.float(), cs)
-    for cfg in (0, 2, 3):
+    for cfg in (0, 2, 3, 5):
         for i, nm in enumerate(("relu+drop CT", "gate CT", "heads", "colsum")):
             a, b = res[cfg][i], res[-2][i]
             err = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
@@ -167,13 +168,13 @@ def bench(d, R, G, iters, B=8, H=12):
         keep.append(arr)
         fl = 2.0 * M * N * K * nprob
         row = f"{name:32s}"
-        for cfg in [-2] + list(range(NCFG)):
+        for cfg in [-2] + list(range(NCFG)) + [-1]:
             force(cfg)
             ms = timeit(lambda: ops.gemm_grouped(BPM_BF16, variant, arr, 7), iters)
             row += f" | {ms * 1e3:7.1f} us {fl / ms / 1e9:6.0f} TF"
         print(row, flush=True)
 
-    print(f"d={d} rows={R} G={G}   columns: " + " | ".join(NAMES[c] for c in [-2] + list(range(NCFG))))
+    print(f"d={d} rows={R} G={G}   columns: " + " | ".join(NAMES[c] for c in [-2] + list(range(NCFG)) + [-1]))
     case("NT 4096^3 plain f32 (1 problem)", GEMM_NT, 4096, 4096, 4096, 4096, 4096, 4096, 1)
     case("NT 8192x8192x4096 CT out", GEMM_NT, 8192, 8192, 4096, 4096, 4096, 8192, 1, out_kind=OUT_CT)
     if os.environ.get("LAB_SHORT"):
