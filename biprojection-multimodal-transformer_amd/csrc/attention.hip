@@ -62,7 +62,7 @@ constexpr int QT = BPM_ATTN_QT;      // queries per tile (dK/dV): a multiple of 
 template <typename CT>
 constexpr int attn_waves(int kernel, int dhp) {
     const bool bf = sizeof(CT) == 2;
-    if (dhp <= 32) return kernel == 0 ? BPM_ATTN_WF : (kernel == 2 && !bf ? 3 : 4);
+    if (dhp <= 32) return kernel == 0 ? (bf ? BPM_ATTN_WF : 4) : (kernel == 2 && !bf ? 3 : 4);
     if (dhp <= 64) return kernel == 0 ? (bf ? 4 : 3) : kernel == 1 ? (bf ? 4 : 3) : (bf ? 3 : 2);
     return kernel == 0 ? (bf ? 3 : 2) : BPM_ATTN_W128;
 }
@@ -83,6 +83,7 @@ struct AProb {
     float dq_scale;
     DropCfg drop;
     int blk0, nblk;     // block prefix / blocks per (b,h)
+    int pair;           // workgroups take two blocks (b, nblk - 1 - b) instead of one
 };
 struct AGroup {
     int nprob;
@@ -158,25 +159,62 @@ BPM_DEV const AProb& pick(const AGroup& grp, int& bid) {
     return grp.p[pi];
 }
 
+// ---------------------------------------------------------------------------
+// Row-contiguous store of one wave's 16 x dh result tile.  The MFMA leaves lane (c = lane & 15, g = lane >> 4) with
+// columns 16n + 4g + r of row c; written from there, every element is its own 2-byte request to L2 (64 lanes x 16
+// instructions per wave): measured on MI355X at B*H = 576 heads of 64, T = S = 512, the forward launch spent 54 of its
+// 105 us in those stores, the dQ pass 98 of 144 (plus the same pattern reading O for delta) and dK/dV 95 of 167 --
+// 19 M requests per output tensor at ~300 G requests/s.  Instead the wave passes the tile through a private LDS block
+// (rows padded by 16 bytes: conflict-free for the 8-byte writes and the 16-byte reads) and stores whole 16-byte chunks
+// with consecutive lanes on consecutive chunks of a row (a 64-wide head row is one 128-byte line per 8 lanes).
+// Head dims that are not whole 16-byte chunks (25 at hidden 300) go element-wise, lanes along the row.
+// Row i of the tile lives at base + i * rstride (elements); rows >= nvalid are not written.
+// ---------------------------------------------------------------------------
+template <typename CT, int DHP>
+BPM_DEV void store_rows16(char* blk, CT* base, size_t rstride, int nvalid, int dh, const f32x4 (&acc)[DHP / 16], float scale, int lane) {
+    constexpr int SZ = sizeof(CT), RS = DHP * SZ + 16, EPC = 16 / SZ;
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < DHP / 16; ++n) {
+        const f32x4 v = acc[n] * scale;
+        char* dst = blk + c * RS + (16 * n + 4 * g) * SZ;
+        if constexpr (SZ == 4) *(f32x4*)dst = v;
+        else { bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3]; *(bf16x4*)dst = o; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: its LDS accesses execute in order; this also pins the compiler
+    const bool wide = (dh % EPC) == 0 && (((uintptr_t)base | (uintptr_t)(rstride * SZ)) & 15) == 0;
+    if (wide) {
+        const int cpr = dh / EPC, total = 16 * cpr;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int row = idx / cpr, ch = idx - row * cpr;
+            if (row < nvalid) *(u32x4*)(base + (size_t)row * rstride + ch * EPC) = *(const u32x4*)(blk + row * RS + ch * 16);
+        }
+    } else {
+        const int total = 16 * dh;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int row = idx / dh, col = idx - row * dh;
+            if (row < nvalid) base[(size_t)row * rstride + col] = *(const CT*)(blk + row * RS + col * SZ);
+        }
+    }
+}
+template <typename CT, int DHP> constexpr int store_rows16_bytes() { return 16 * (DHP * (int)sizeof(CT) + 16); }
+
 BPM_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32: exp2(-inf) = 0, no denormal fix-up
 
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(0, DHP), attn_waves<CT>(0, DHP)))) void attn_fwd_kernel(const AGroup grp) {
+BPM_DEV void attn_fwd_block(const AProb& P, char* smem, const int bh, const int qb) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
-    __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
     char* kimg = smem;
     char* vimg = smem + KT * C::STRIDE;
 
-    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const AProb& P = pick(grp, bid);
-    const int bh = bid / P.nblk, qb = bid % P.nblk;
     const int b = bh / P.H, h = bh % P.H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                 // per-lane values are re-derived in each pass of the block-pair loop, not kept live across it
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int q0 = qb * 64 + wave * 16;               // wave-uniform first query
     const int q = q0 + c;                             // this lane's query
@@ -285,17 +323,31 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
     }
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
-    if (q < P.T) {
-        const float inv = 1.f / l_run;
-        CT* orow = (CT*)P.O + ((size_t)q * P.B + b) * P.ldo + h * P.dh;
-#pragma unroll
-        for (int n = 0; n < C::ND; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 16 * n + 4 * g + r;
-                if (d < P.dh) orow[d] = Tr<CT>::from_f(o[n][r] * inv);
-            }
-        if (g == 0) P.lse[(size_t)bh * P.T + q] = m_run + logf(l_run);
+    if (q < P.T && g == 0) P.lse[(size_t)bh * P.T + q] = m_run + logf(l_run);
+    static_assert(2 * KT * C::STRIDE >= 4 * store_rows16_bytes<CT, DHP>(), "one transpose block per wave in the K / V images");
+    __syncthreads();                                   // every wave is done with the K / V images
+    if (q0 < P.T)
+        store_rows16<CT, DHP>(smem + wave * store_rows16_bytes<CT, DHP>(), (CT*)P.O + ((size_t)q0 * P.B + b) * P.ldo + h * P.dh,
+                              (size_t)P.B * P.ldo, P.T - q0, P.dh, o, 1.f / l_run, lane);
+}
+
+// Two 64-row blocks per workgroup, b and nblk - 1 - b: under the future mask block b has b + 1 (forward / dQ) or nblk - b
+// (dK / dV) tiles, so every pair carries the same work, and the per-block lead-in (operand loads, first tile, result
+// store: ~6 us of latency that four resident workgroups per CU cannot hide) is paid half as often.  Measured on MI355X,
+// 576 heads of 64, T = S = 512, masked: see DESIGN.md section 5 (attention).
+template <typename CT, int DHP>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(0, DHP), attn_waves<CT>(0, DHP)))) void attn_fwd_kernel(const AGroup grp) {
+    typedef Cfg<CT, DHP> C;
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const AProb& P = pick(grp, bid);
+    const int nb2 = P.pair ? (P.nblk + 1) >> 1 : P.nblk;
+    const int bh = bid / nb2, first = P.pair ? bid % nb2 : P.nblk - 1 - bid % nb2, second = P.pair ? P.nblk - 1 - first : first;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass && second == first) break;
+        attn_fwd_block<CT, DHP>(P, smem, bh, pass ? second : first);
     }
 }
 
@@ -303,19 +355,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 // backward, dQ (and delta = rowsum(dO * O))
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(1, DHP), attn_waves<CT>(1, DHP)))) void attn_bwd_dq_kernel(const AGroup grp) {
+BPM_DEV void attn_bwd_dq_block(const AProb& P, char* smem, const int bh, const int qb) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
-    __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
     char* kimg = smem;
     char* vimg = smem + KT * C::STRIDE;
 
-    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const AProb& P = pick(grp, bid);
-    const int bh = bid / P.nblk, qb = bid % P.nblk;
     const int b = bh / P.H, h = bh % P.H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                 // per-lane values are re-derived in each pass of the block-pair loop, not kept live across it
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int q0 = qb * 64 + wave * 16;
     const int q = q0 + c;
@@ -326,16 +375,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 
     frag qf[C::NKS], dof[C::NKS];
     float delta = 0.f;
+    const bool o_wide = (P.dh % Tr<CT>::EPC) == 0 && (((uintptr_t)P.O | (uintptr_t)((size_t)P.ldo * C::SZ)) & 15) == 0;
 #pragma unroll
     for (int s = 0; s < C::NKS; ++s) {
         qf[s] = load_frag<CT, DHP>(Qh, q, P.T, s, g);
         dof[s] = load_frag<CT, DHP>(dOh, q, P.T, s, g);
         if (q < P.T) {
             const CT* orow = (const CT*)P.O + ((size_t)q * P.B + b) * P.ldo + h * P.dh;
+            const int d0 = s * Tr<CT>::KSTEP + g * Tr<CT>::EPC;
+            if (o_wide) {                              // whole 16-byte chunks of the O row (element loads: one L2 request each)
+                if (d0 < P.dh) {
+                    const frag of = *(const frag*)(orow + d0);
 #pragma unroll
-            for (int j = 0; j < Tr<CT>::EPC; ++j) {
-                const int d = s * Tr<CT>::KSTEP + g * Tr<CT>::EPC + j;
-                if (d < P.dh) delta += Tr<CT>::to_f(dof[s][j]) * Tr<CT>::to_f(orow[d]);
+                    for (int j = 0; j < Tr<CT>::EPC; ++j) delta += Tr<CT>::to_f(dof[s][j]) * Tr<CT>::to_f(of[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < Tr<CT>::EPC; ++j)
+                    if (d0 + j < P.dh) delta += Tr<CT>::to_f(dof[s][j]) * Tr<CT>::to_f(orow[d0 + j]);
             }
         }
     }
@@ -414,15 +471,29 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
         __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
 #endif
     }
-    if (q < P.T) {
-        CT* row = (CT*)P.dQ + ((size_t)q * P.B + b) * P.lddq + h * P.dh;
-#pragma unroll
-        for (int n = 0; n < C::ND; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 16 * n + 4 * g + r;
-                if (d < P.dh) row[d] = Tr<CT>::from_f(dq[n][r] * P.dq_scale);
-            }
+    __syncthreads();                                   // every wave is done with the K / V images
+    if (q0 < P.T)
+        store_rows16<CT, DHP>(smem + wave * store_rows16_bytes<CT, DHP>(), (CT*)P.dQ + ((size_t)q0 * P.B + b) * P.lddq + h * P.dh,
+                              (size_t)P.B * P.lddq, P.T - q0, P.dh, dq, P.dq_scale, lane);
+}
+
+// Two 64-row blocks per workgroup, b and nblk - 1 - b: under the future mask block b has b + 1 (forward / dQ) or nblk - b
+// (dK / dV) tiles, so every pair carries the same work, and the per-block lead-in (operand loads, first tile, result
+// store: ~6 us of latency that four resident workgroups per CU cannot hide) is paid half as often.  Measured on MI355X,
+// 576 heads of 64, T = S = 512, masked: see DESIGN.md section 5 (attention).
+template <typename CT, int DHP>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(1, DHP), attn_waves<CT>(1, DHP)))) void attn_bwd_dq_kernel(const AGroup grp) {
+    typedef Cfg<CT, DHP> C;
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const AProb& P = pick(grp, bid);
+    const int nb2 = P.pair ? (P.nblk + 1) >> 1 : P.nblk;
+    const int bh = bid / nb2, first = P.pair ? bid % nb2 : P.nblk - 1 - bid % nb2, second = P.pair ? P.nblk - 1 - first : first;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass && second == first) break;
+        attn_bwd_dq_block<CT, DHP>(P, smem, bh, pass ? second : first);
     }
 }
 
@@ -430,21 +501,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 // backward, dK and dV
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(2, DHP), attn_waves<CT>(2, DHP)))) void attn_bwd_dkv_kernel(const AGroup grp) {
+BPM_DEV void attn_bwd_dkv_block(const AProb& P, char* smem, const int bh, const int kb) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
-    __shared__ __attribute__((aligned(16))) char smem[2 * QT * C::STRIDE + 2 * QT * 4];
     char* qimg = smem;
     char* doimg = smem + QT * C::STRIDE;
     float* s_lse = (float*)(smem + 2 * QT * C::STRIDE);      // -lse * log2(e)
     float* s_del = s_lse + QT;
 
-    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const AProb& P = pick(grp, bid);
-    const int bh = bid / P.nblk, kb = bid % P.nblk;
     const int b = bh / P.H, h = bh % P.H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                 // per-lane values are re-derived in each pass of the block-pair loop, not kept live across it
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int j0 = kb * 64 + wave * 16;                // wave-uniform first key
     const int j = j0 + c;                              // this lane's key
@@ -542,23 +610,40 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
         __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
 #endif
     }
-    if (j < P.S) {
-        CT* krow = (CT*)P.dK + ((size_t)j * P.B + b) * P.lddk + h * P.dh;
-        CT* vrow = (CT*)P.dV + ((size_t)j * P.B + b) * P.lddv + h * P.dh;
-#pragma unroll
-        for (int n = 0; n < C::ND; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = 16 * n + 4 * g + r;
-                if (d < P.dh) {
-                    krow[d] = Tr<CT>::from_f(dk[n][r]);
-                    vrow[d] = Tr<CT>::from_f(dv[n][r]);
-                }
-            }
+    static_assert(2 * QT * C::STRIDE >= 4 * store_rows16_bytes<CT, DHP>(), "one transpose block per wave in the Q / dO images");
+    __syncthreads();                                   // every wave is done with the Q / dO images
+    if (j0 < P.S) {
+        char* blk = smem + wave * store_rows16_bytes<CT, DHP>();
+        store_rows16<CT, DHP>(blk, (CT*)P.dK + ((size_t)j0 * P.B + b) * P.lddk + h * P.dh, (size_t)P.B * P.lddk, P.S - j0, P.dh, dk, 1.f, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the block is read out before dV overwrites it
+        store_rows16<CT, DHP>(blk, (CT*)P.dV + ((size_t)j0 * P.B + b) * P.lddv + h * P.dh, (size_t)P.B * P.lddv, P.S - j0, P.dh, dv, 1.f, lane);
     }
 }
 
-int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S, uint64_t seed, int* total) {
+// Two 64-row blocks per workgroup, b and nblk - 1 - b: under the future mask block b has b + 1 (forward / dQ) or nblk - b
+// (dK / dV) tiles, so every pair carries the same work, and the per-block lead-in (operand loads, first tile, result
+// store: ~6 us of latency that four resident workgroups per CU cannot hide) is paid half as often.  Measured on MI355X,
+// 576 heads of 64, T = S = 512, masked: see DESIGN.md section 5 (attention).
+template <typename CT, int DHP>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(2, DHP), attn_waves<CT>(2, DHP)))) void attn_bwd_dkv_kernel(const AGroup grp) {
+    typedef Cfg<CT, DHP> C;
+    __shared__ __attribute__((aligned(16))) char smem[2 * QT * C::STRIDE + 2 * QT * 4];
+    if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const AProb& P = pick(grp, bid);
+    const int nb2 = P.pair ? (P.nblk + 1) >> 1 : P.nblk;
+    const int bh = bid / nb2, first = P.pair ? bid % nb2 : bid % nb2, second = P.pair ? P.nblk - 1 - first : first;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass && second == first) break;
+        attn_bwd_dkv_block<CT, DHP>(P, smem, bh, pass ? second : first);
+    }
+}
+
+// tuning hook (tools/attn_lab.py): bit k = kernel k (0 forward, 1 dQ, 2 dK/dV) pairs blocks
+int g_attn_pair = 7;
+
+int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S, uint64_t seed, int* total, int kernel) {
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
     g.nprob = nprob;
     int blk = 0;
@@ -581,7 +666,8 @@ int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S,
         p.drop = bpm_make_drop(q.drop_p, seed, q.drop_site);
         p.nblk = ((blocks_over_S ? q.S : q.T) + 63) / 64;
         p.blk0 = blk;
-        blk += p.nblk * q.B * q.H;
+        p.pair = (g_attn_pair >> kernel) & 1;
+        blk += (p.pair ? (p.nblk + 1) >> 1 : p.nblk) * q.B * q.H;
     }
     *total = blk;
     return 0;
@@ -627,10 +713,16 @@ int dispatch(int which, int dhp, const AGroup& g, int total, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int bpm_debug_attn_pair(int mask) {
+    if (mask < 0 || mask > 7) return BPM_ERR_ARG;
+    g_attn_pair = mask;
+    return 0;
+}
+
 extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
     AGroup g;
     int total = 0;
-    int rc = fill(g, probs, nprob, 0, seed, &total);
+    int rc = fill(g, probs, nprob, 0, seed, &total, 0);
     if (rc) return rc;
     for (int i = 0; i < nprob; ++i)
         if (!probs[i].Q || !probs[i].K || !probs[i].V || !probs[i].O || !probs[i].lse) return BPM_ERR_ARG;
@@ -644,7 +736,7 @@ extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob,
 static int attn_bwd_parts(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream, int parts) {
     AGroup g;
     int total = 0;
-    int rc = fill(g, probs, nprob, 0, seed, &total);
+    int rc = fill(g, probs, nprob, 0, seed, &total, 1);
     if (rc) return rc;
     for (int i = 0; i < nprob; ++i) {
         const bpm_attn_problem& q = probs[i];
@@ -661,7 +753,7 @@ static int attn_bwd_parts(int dtype, const bpm_attn_problem* probs, int nprob, u
         if (rc) return rc;
     }
     if (parts & 2) {
-        rc = fill(g, probs, nprob, 1, seed, &total);
+        rc = fill(g, probs, nprob, 1, seed, &total, 2);
         if (rc) return rc;
         BpmProfScope prof(BPM_K_ATTN_BWD_DKV, s, w);
         rc = dtype == BPM_BF16 ? dispatch<bf16_t>(2, probs[0].dhp, g, total, s) : dispatch<float>(2, probs[0].dhp, g, total, s);
