@@ -64,34 +64,43 @@ BPM_DEV void flush_colsum_wide(const Prob& P, f32x4 cs, int nb, int lane) {
     }
 }
 
-// rows mrow + 4 * i (i < NI), columns nb .. nb + 3
+// side operands of rows mrow + 4 * i (i < NI), columns nb .. nb + 3: requested one 16-row step ahead of their use (the
+// epilogue of a wave tile is a chain of TMW such steps, each a ~2 us round trip to memory when the loads sit right before
+// the arithmetic: 10 steps at 160 rows per wave cost as much as the 12-stage main loop of a K = 768 product)
 template <int NI>
-BPM_DEV void epilogue_wide(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NI], f32x4& csum) {
-    const bool colok = nb < P.N;
-    const uint32_t nbc = colok ? (uint32_t)nb : 0u;
-    const bool f32out = P.out_kind == BPM_OUT_F32;
-    const bool accum = f32out && (P.flags & BPM_GEMM_ACCUM);
-    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+struct WideSide {
     f32x4 addv[NI];
     bf16x4 gt[NI];
-    if (P.bias_n) bias = *(const f32x4*)(P.bias_n + nbc);
+};
+
+template <int NI>
+BPM_DEV void wide_load(const Prob& P, int mrow, int nb, WideSide<NI>& s) {
+    const uint32_t nbc = nb < P.N ? (uint32_t)nb : 0u;
+    const bool accum = P.out_kind == BPM_OUT_F32 && (P.flags & BPM_GEMM_ACCUM);
     if (P.gate) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) gt[i] = *(const bf16x4*)((const bf16_t*)P.gate + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldg + nbc);
+        for (int i = 0; i < NI; ++i) s.gt[i] = *(const bf16x4*)((const bf16_t*)P.gate + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldg + nbc);
     } else {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) gt[i] = bf16x4{};
+        for (int i = 0; i < NI; ++i) s.gt[i] = bf16x4{};
     }
     if (P.resid) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) addv[i] = *(const f32x4*)(P.resid + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldr + nbc);
+        for (int i = 0; i < NI; ++i) s.addv[i] = *(const f32x4*)(P.resid + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldr + nbc);
     } else if (accum) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) addv[i] = *(const f32x4*)((const float*)P.C + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldc + nbc);
+        for (int i = 0; i < NI; ++i) s.addv[i] = *(const f32x4*)((const float*)P.C + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldc + nbc);
     } else {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) addv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NI; ++i) s.addv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+}
+
+// rows mrow + 4 * i (i < NI), columns nb .. nb + 3
+template <int NI>
+BPM_DEV void wide_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NI], const f32x4 bias, const WideSide<NI>& s, f32x4& csum) {
+    const bool colok = nb < P.N;
+    const bool f32out = P.out_kind == BPM_OUT_F32;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const EpiRow e = epi_row(P, mrow + 4 * i);
@@ -106,7 +115,7 @@ BPM_DEV void epilogue_wide(const Prob& P, int mrow, int nb, const f32x4 (&acc)[N
             }
             if (P.gate) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = (float)gt[i][q] > 0.f ? x[q] * P.gate_scale : 0.f;
+                for (int q = 0; q < 4; ++q) x[q] = (float)s.gt[i][q] > 0.f ? x[q] * P.gate_scale : 0.f;
             }
             if (P.drop.thresh != 0) {
                 float d0, d1, d2, d3;
@@ -115,7 +124,7 @@ BPM_DEV void epilogue_wide(const Prob& P, int mrow, int nb, const f32x4 (&acc)[N
                 x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
             }
             csum += x;
-            x += addv[i];
+            x += s.addv[i];
         }
         if (f32out) {
             if (valid) *(f32x4*)((float*)P.C + e.offc + nb) = x;
@@ -345,6 +354,13 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     const int lr = lane >> 4, lc = lane & 15;
     const int nbw = n0 + wn * 64 + 4 * lc;
     f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (P.bias_n) bias = *(const f32x4*)(P.bias_n + (nbw < P.N ? nbw : 0));
+    // side operands of 16-row step h live in sd[h & 1], requested during step h - 1 -- where the register budget allows:
+    // the 16-wave configuration (128 registers) spills with two sets and requests them right before their use
+    constexpr bool AHEAD = NW < 16;
+    WideSide<4> sd[2];
+    if constexpr (AHEAD) wide_load<4>(P, mw + lr, nbw, sd[0]);
     auto pass = [&](auto PB) {             // rows 32 PB .. 32 PB + 31 of the wave tile
         constexpr int pb = decltype(PB)::value;
         if constexpr (pb < TMW / 2) {
@@ -357,13 +373,16 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
                 }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {           // 16 rows at a time: 4 row steps per lane in flight
+                const int h = 2 * pb + hf;
+                if constexpr (AHEAD) { if (h + 1 < TMW) wide_load<4>(P, mw + 16 * (h + 1) + lr, nbw, sd[(hf + 1) & 1]); }
+                else wide_load<4>(P, mw + 16 * h + lr, nbw, sd[hf & 1]);
                 f32x4 v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 16 * hf + 4 * i + lr;
                     v[i] = *(const f32x4*)(blk + row * 256 + ((lc ^ (row & 15)) << 4));
                 }
-                epilogue_wide<4>(P, mw + 32 * pb + 16 * hf + lr, nbw, v, cs);
+                wide_apply<4>(P, mw + 16 * h + lr, nbw, v, bias, sd[hf & 1], cs);
             }
         }
     };
