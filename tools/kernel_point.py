@@ -93,7 +93,7 @@ def measure(dev="cuda", d=768, H=6, T=50, S=50, B=64, G=6, iters=20):
             "why_short_of_target": "98 % of the block's flops are four 768 x 768 projections per 50-row sequence; one 64-row workgroup per "
                                    "(encoder, batch element) needs 6 LDS-DMA instructions per 16 MFMAs and is paced by their issue cost "
                                    "(~150 cycles each), and 384 workgroups of 144 KB LDS run in two rounds on 256 CUs; the grouped GEMMs "
-                                   "amortise the same weight bytes over 3200-row problems but stop at ~430 TFLOP/s for K = N = 768 "
+                                   "amortise the same weight bytes over 3200-row problems but stop at ~500 TFLOP/s for K = N = 768 "
                                    "(main loop and fp32 epilogue do not overlap: DESIGN.md section 5)"}
 
 
