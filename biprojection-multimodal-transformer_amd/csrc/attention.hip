@@ -53,17 +53,27 @@ constexpr int KT = 64;      // keys per tile (forward / dQ)
 #ifndef BPM_ATTN_QT
 #define BPM_ATTN_QT 64
 #endif
+#ifndef BPM_ATTN_DKV_W32
+#define BPM_ATTN_DKV_W32 3
+#endif
+#ifndef BPM_ATTN_DKV_W64
+#define BPM_ATTN_DKV_W64 2
+#endif
+#ifndef BPM_ATTN_DQ_W64
+#define BPM_ATTN_DQ_W64 3
+#endif
 constexpr int QT = BPM_ATTN_QT;      // queries per tile (dK/dV): a multiple of 32
 
 // Waves per SIMD each kernel is compiled for (register budget 512 / waves), per kernel (0 forward, 1 dQ, 2 dK/dV),
-// compute type and padded head_dim: the largest occupancy at which the kernel does not spill.  At head_dim 64 (hidden
-// 768 / 12 heads) the bf16 dK/dV kernel spilled 128 bytes per lane at 4 waves; at 3 (166 registers) the backward pass of
-// the headline workload went 457 -> 346 us per launch.  The f32 (parity-mode) kernels need one wave fewer throughout.
+// compute type and padded head_dim: the largest occupancy at which the kernel does not spill inside its tile loop.
+// Measured on MI355X (tools/attn_lab.py, six encoders, B*H = 96 heads each, T = S = 512, masked), bf16: dQ at head_dim 64
+// 110 us at 4 waves (12 registers spilled) -> 98 at 3; dK/dV at head_dim 64 150 us at 3 waves (20 spilled) -> 144 at 2;
+// dK/dV at head_dim 25 127 us at 4 waves (25 spilled) -> 118 at 3.  The f32 (parity-mode) kernels need one wave fewer.
 template <typename CT>
 constexpr int attn_waves(int kernel, int dhp) {
     const bool bf = sizeof(CT) == 2;
-    if (dhp <= 32) return kernel == 0 ? (bf ? BPM_ATTN_WF : 4) : (kernel == 2 && !bf ? 3 : 4);
-    if (dhp <= 64) return kernel == 0 ? (bf ? 4 : 3) : kernel == 1 ? (bf ? 4 : 3) : (bf ? 3 : 2);
+    if (dhp <= 32) return kernel == 0 ? (bf ? BPM_ATTN_WF : 4) : (kernel == 2 ? (bf ? BPM_ATTN_DKV_W32 : 3) : 4);
+    if (dhp <= 64) return kernel == 0 ? (bf ? 4 : 3) : kernel == 1 ? (bf ? BPM_ATTN_DQ_W64 : 3) : (bf ? BPM_ATTN_DKV_W64 : 2);
     return kernel == 0 ? (bf ? 3 : 2) : BPM_ATTN_W128;
 }
 constexpr float LOG2E = 1.4426950408889634f;

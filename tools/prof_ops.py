@@ -2,7 +2,7 @@ import sys, os, torch
 sys.path.insert(0, os.getcwd()); sys.argv=["x"]
 import bench, bpmult_amd
 from bpmult_amd.models import get_model
-c = bench.CONFIGS["cfg1"]; dev = torch.device("cuda", 0)
+c = bench.CONFIGS[os.environ.get("PROF_CFG", "h768")]; dev = torch.device("cuda", 0)
 model = get_model(bench.model_args(c, "bf16")).to(dev).train()
 batch = bench.synth_batch(c, c["batch"], 1234, dev)
 crit = torch.nn.BCEWithLogitsLoss()
