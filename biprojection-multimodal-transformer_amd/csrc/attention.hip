@@ -248,7 +248,7 @@ BPM_DEV void attn_fwd_block(const AProb& P, char* smem, const int bh, const int 
     const int lim_min = min(P.S, P.qpos0 + q0 * P.qstride + P.mask_off);     // every lane of the wave sees keys j < lim_min
     const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
-    const bool pair_ok = (P.S & 1) == 0;               // row starts are even: keys (2m, 2m+1) are hash pairs
+    const bool pair_ok = (P.S & 3) == 0;               // row starts are multiples of 4: keys (4m .. 4m+3) are one hash quad
 
     RowStage<CT, DHP, KT> kst, vst;
     if (ntile > 0) { kst.load(Kh, 0, P.S, tid); vst.load(Vh, 0, P.S, tid); }
@@ -298,12 +298,11 @@ BPM_DEV void attn_fwd_block(const AProb& P, char* smem, const int bh, const int 
         }
         const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         if (dropping) {
-            if (pair_ok) {                             // wave-uniform: (r, r+1) share one hash
+            if (pair_ok) {                             // wave-uniform: r = 0..3 share one hash
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     float d0, d1, d2, d3;
-                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n), d0, d1);
-                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n + 2), d2, d3);
+                    bpm_drop_mult4(P.drop, drow + (uint32_t)(jb + 16 * n), d0, d1, d2, d3);
                     st[n] *= f32x4{d0, d1, d2, d3};
                 }
             } else {
@@ -422,7 +421,7 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, char* smem, const int bh, const i
     const int lim_min = min(P.S, P.qpos0 + q0 * P.qstride + P.mask_off);
     const bool dropping = P.drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
-    const bool pair_ok = (P.S & 1) == 0;               // row starts are even: keys (2m, 2m+1) are hash pairs
+    const bool pair_ok = (P.S & 3) == 0;               // row starts are multiples of 4: keys (4m .. 4m+3) are one hash quad
 
     RowStage<CT, DHP, KT> kst, vst;
     if (ntile > 0) { kst.load(Kh, 0, P.S, tid); vst.load(Vh, 0, P.S, tid); }
@@ -448,8 +447,7 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, char* smem, const int bh, const i
             float dm[4] = {1.f, 1.f, 1.f, 1.f};
             if (dropping) {
                 if (pair_ok) {
-                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n), dm[0], dm[1]);
-                    bpm_drop_mult2(P.drop, drow + (uint32_t)(jb + 16 * n + 2), dm[2], dm[3]);
+                    bpm_drop_mult4(P.drop, drow + (uint32_t)(jb + 16 * n), dm[0], dm[1], dm[2], dm[3]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dm[r] = bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));

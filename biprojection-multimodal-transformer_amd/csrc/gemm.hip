@@ -173,9 +173,8 @@ BPM_DEV void epilogue_tile(const Prob& P, bool lead, int m, int nb, const f32x4&
     float dm[4] = {1.f, 1.f, 1.f, 1.f};
     if (P.drop.thresh != 0) {
         const uint32_t i0 = (uint32_t)m * (uint32_t)P.N + (uint32_t)nb;
-        if ((i0 & 1u) == 0) {                       // (nb, nb+1) and (nb+2, nb+3) are hash pairs
-            bpm_drop_mult2(P.drop, i0, dm[0], dm[1]);
-            bpm_drop_mult2(P.drop, i0 + 2, dm[2], dm[3]);
+        if ((i0 & 3u) == 0) {                       // nb .. nb+3 is one hash quad
+            bpm_drop_mult4(P.drop, i0, dm[0], dm[1], dm[2], dm[3]);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) dm[q] = bpm_drop_mult(P.drop, i0 + q);
@@ -331,10 +330,9 @@ BPM_DEV void epi_fast_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[
 #pragma unroll
                 for (int q = 0; q < 4; ++q) x[q] = (float)s.gt[b][q] > 0.f ? x[q] * P.gate_scale : 0.f;
             }
-            if (P.drop.thresh != 0) {                   // m*N + nb is even: two hash pairs
+            if (P.drop.thresh != 0) {                   // m*N + nb is a multiple of 4: one hash quad
                 float d0, d1, d2, d3;
-                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb, d0, d1);
-                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb + 2u, d2, d3);
+                bpm_drop_mult4(P.drop, e.didx + (uint32_t)nb, d0, d1, d2, d3);
                 x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
             }
             csum += x;

@@ -119,8 +119,7 @@ BPM_DEV void wide_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NI],
             }
             if (P.drop.thresh != 0) {
                 float d0, d1, d2, d3;
-                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb, d0, d1);
-                bpm_drop_mult2(P.drop, e.didx + (uint32_t)nb + 2u, d2, d3);
+                bpm_drop_mult4(P.drop, e.didx + (uint32_t)nb, d0, d1, d2, d3);
                 x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
             }
             csum += x;

@@ -472,11 +472,10 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int 
                     *(f32x4*)(P.dx + (size_t)row * d + 4 * q) = v;
                     if (fused) {
                         f32x4 m = v;
-                        if (P.drop.thresh != 0) {   // row*d + 4q is even: two hash pairs
+                        if (P.drop.thresh != 0) {   // row*d + 4q is a multiple of 4 (d % 4 == 0): one hash quad
                             float d0, d1, d2, d3;
                             const uint32_t i0 = (uint32_t)row * (uint32_t)d + 4u * (uint32_t)q;
-                            bpm_drop_mult2(P.drop, i0, d0, d1);
-                            bpm_drop_mult2(P.drop, i0 + 2u, d2, d3);
+                            bpm_drop_mult4(P.drop, i0, d0, d1, d2, d3);
                             m[0] *= d0; m[1] *= d1; m[2] *= d2; m[3] *= d3;
                         }
                         put4<CT>(P.cast, (size_t)row * P.ldc + 4 * q, m);

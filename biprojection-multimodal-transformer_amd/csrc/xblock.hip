@@ -297,8 +297,7 @@ __global__ __launch_bounds__(XT) void xblock_fwd_kernel(const XGroup grp) {
                 f32x4 v = acc[a][bt] + bo;
                 if (P.rdrop.thresh != 0) {
                     float d0, d1, d2, d3;
-                    bpm_drop_mult2(P.rdrop, m * (uint32_t)d + (uint32_t)n, d0, d1);
-                    bpm_drop_mult2(P.rdrop, m * (uint32_t)d + (uint32_t)n + 2u, d2, d3);
+                    bpm_drop_mult4(P.rdrop, m * (uint32_t)d + (uint32_t)n, d0, d1, d2, d3);
                     v[0] *= d0; v[1] *= d1; v[2] *= d2; v[3] *= d3;
                 }
                 v += *(const f32x4*)(P.resid + (size_t)m * d + n);

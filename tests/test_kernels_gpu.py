@@ -60,15 +60,19 @@ def drop_mult(shape, p, seed, site):
         return torch.ones(shape)
     n = int(np.prod(shape))
     idx = np.arange(n, dtype=np.uint64)
-    odd = (idx & 1).astype(bool)
-    h = ((idx >> 1) * 0x9E3779B1 + host_key(seed, site)) & 0xFFFFFFFF
-    h ^= h >> 16
-    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
-    h ^= h >> 13
-    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
-    h ^= h >> 16
+    M = 0xFFFFFFFF
+    a = ((idx >> 2) + host_key(seed, site)) & M
+    a ^= a >> 16
+    a = (a * 0x85EBCA6B) & M
+    a ^= a >> 13
+    w0 = (a * 0xC2B2AE35) & M
+    w0 ^= w0 >> 16
+    w1 = (a * 0x27D4EB2F) & M
+    w1 ^= w1 >> 15
+    w = np.where((idx & 2).astype(bool), w1, w0)
+    bits = np.where((idx & 1).astype(bool), w >> 16, w & 0xFFFF)
     thresh = int(p * 65536.0 + 0.5)
-    keep = np.where(odd, h >> 16, h & 0xFFFF) >= thresh
+    keep = bits >= thresh
     return torch.from_numpy(np.where(keep, 1.0 / (1.0 - p), 0.0).astype(np.float32)).reshape(shape)
 
 

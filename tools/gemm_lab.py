@@ -163,7 +163,7 @@ def bench(d, R, G, iters, B=8, H=12):
                 ex["heads"] = (B, H, M // B, dh, dhp)
             keep.extend([A_, B_, C_] + [v for v in ex.values() if torch.is_tensor(v)])
             probs.append(ops.gemm_problem(A_, B_, C_, M, N, K, lda, ldb, ldc, out_kind=ok, flags=kw.get("flags", 0) | F_KPAD,
-                                          drop_p=kw.get("drop_p", 0.0), drop_site=3, **ex))
+                                          drop_p=0.0 if os.environ.get("LAB_NODROP") else kw.get("drop_p", 0.0), drop_site=3, **ex))
         arr = ops.array(ops.GemmProblem, probs)
         keep.append(arr)
         fl = 2.0 * M * N * K * nprob
