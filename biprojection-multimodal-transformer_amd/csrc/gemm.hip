@@ -843,10 +843,10 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     }
     // LDS-DMA kernel (gemm_dma.h): bf16, no split-K, k-contiguous operands hold whole 128-byte stages inside their
     // zero-padded rows, epilogue 4-wide.  Measured on MI355X at hidden 768, six problems of 4096 rows per launch
-    // (tools/gemm_lab.py, us, register-staged 128 x 64 kernel -> 256 x 256 tile): q 84 -> 70, k/v 154 -> 108, out 80 ->
-    // 76, fc1 267 -> 172, fc2 245 -> 195, d(fc2) 314 -> 190, d(fc1) 185 -> 167, d(out) 82 -> 72, d(k/v) 135 -> 114,
-    // FFN weight gradients 445 -> 399 (8 waves of 128 x 64); the attention weight gradients (768 x 768 x 4096: nine
-    // 256 x 256 tiles per problem) stay on the 128 x 64 kernel (154 against 191).
+    // (tools/gemm_lab.py, us, register-staged 128 x 64 kernel -> the configuration chosen below): q 84 -> 55, k/v 154 ->
+    // 103, out 80 -> 55, fc1 267 -> 156, fc2 245 -> 124, d(fc2) 314 -> 181, d(fc1) 185 -> 110, d(out) 82 -> 55, d(q) 63 ->
+    // 47, d(k/v) 135 -> 107, FFN weight gradients 445 -> 322 (8 waves of 128 x 64); the attention weight gradients
+    // (768 x 768 x 4096: nine 256 x 256 tiles per problem) stay on the 128 x 64 kernel (154 against 186).
     int dma = -1;
     if (dtype == BPM_BF16 && fast && g_force_dma != -2) {
         bool legal = true, big = true;
