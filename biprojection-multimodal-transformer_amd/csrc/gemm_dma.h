@@ -26,7 +26,8 @@
 //     ds_read_b64_tr_b16 reads of the 16x16x32 operand (a half's two blocks are 8 k-rows apart).
 // An LDS-DMA piece lands lane-linear (base + 16 * lane), so the swizzle is applied to the per-lane SOURCE address and
 // again on the read -- never to the destination (rule 21 of the guide).
-// Bounds: rows past M / k-rows past K are cut off by the buffer descriptor's range check (returns zeros); column
+// Bounds: rows past M / k-rows past K are cut off by the buffer descriptor's range check (returns zeros; probed on
+// gfx950: the check covers voffset + soffset, so the wave-uniform piece / stage offsets in soffset are checked too); column
 // overhang of a k-strided operand only reaches output columns the epilogue masks.  k-contiguous operands must keep
 // whole 128-byte stages inside their zero-padded rows (checked by the dispatcher).
 
