@@ -310,6 +310,41 @@ def test_attention_fwd_bwd(dtype, B, H, T, S, dh, masked, pdrop):
     close(rows(dV, S), v.grad, tb, "dV")
 
 
+
+@pytest.mark.parametrize("T,S,dh", [(320, 320, 64), (65, 200, 25), (513, 512, 64), (64, 64, 128)])
+def test_attention_block_pairing_is_bitwise_neutral(T, S, dh):
+    """A workgroup of the attention kernels takes two 64-row blocks (b, nblk-1-b); the tuning hook switches every kernel
+    back to one block per workgroup.  Both schedules run the same per-block code, so O, LSE, dQ, dK, dV must be
+    bit-identical -- odd block counts (the middle block is alone), one block, masked and with dropout."""
+    import ctypes as C
+    from bpmult_amd import _lib
+    L = _lib.lib()
+    L.bpm_debug_attn_pair.argtypes = [C.c_int]
+    B, H = 2, 2
+    dhp = 32 if dh <= 32 else (64 if dh <= 64 else 128)
+    ctt, d = torch.bfloat16, H * dh
+    ld = pad32(d)
+    mk = lambda L_, seed: torch.cat([rnd(B, H, L_, dh, seed=seed) * 0.5, torch.zeros(B, H, L_, dhp - dh)], -1).to(ctt).to(DEV)
+    Q, K, V, dO = mk(T, 41), mk(S, 42), mk(S, 43), mk(T, 44)
+    res = {}
+    try:
+        for mode in (7, 0):
+            _lib.check(L.bpm_debug_attn_pair(mode), "bpm_debug_attn_pair")
+            O = torch.zeros(T * B, ld, device=DEV, dtype=ctt)
+            lse, delta = torch.zeros(B, H, T, device=DEV), torch.zeros(B, H, T, device=DEV)
+            dQ, dK, dV = (torch.zeros(n * B, ld, device=DEV, dtype=ctt) for n in (T, S, S))
+            p = ops.attn_problem(Q, K, V, O, ld, lse, B, H, T, S, dh, dhp, 1 + abs(S - T), dO=dO, delta=delta, dQ=dQ, lddq=ld,
+                                 dK=dK, lddk=ld, dV=dV, lddv=ld, dq_scale=dh ** -0.5, drop_p=0.1, drop_site=4)
+            ops.attn_fwd(BPM_BF16, [p], seed=11)
+            ops.attn_bwd(BPM_BF16, [p], seed=11)
+            torch.cuda.synchronize()
+            res[mode] = [t.float().cpu() for t in (O, lse, dQ, dK, dV)]
+    finally:
+        L.bpm_debug_attn_pair(7)
+    for a, b, nm in zip(res[7], res[0], ("O", "lse", "dQ", "dK", "dV")):
+        assert torch.isfinite(a).all(), nm
+        assert torch.equal(a, b), f"{nm}: paired and unpaired schedules differ"
+
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DT)
 def test_pack_rows_and_embed_pos(dtype):
