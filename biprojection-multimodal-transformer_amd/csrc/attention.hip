@@ -132,14 +132,17 @@ struct RowStage {
     static constexpr int N = ROWS * C::CPR;
     static constexpr int PT = (N + NTHREADS - 1) / NTHREADS;
     u32x4 r[PT];
+    // `src` is wave-uniform (a head's first row): buffer loads through a descriptor of nrows rows, so rows past the end
+    // come back as zeros from the range check instead of a clamp + select per dword (16 v_cndmask per tile and wave)
     BPM_DEV void load(const char* src, int row0, int nrows, int tid) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nrows * C::ROWB, 0x00020000);
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int c = tid + i * NTHREADS;
             const int row = c / C::CPR, cc = c % C::CPR;
-            const bool ok = c < N && row0 + row < nrows;
-            const u32x4 v = *(const u32x4*)(src + (size_t)(ok ? row0 + row : 0) * C::ROWB + cc * 16);
-            r[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+            int voff = (row0 + row) * C::ROWB + cc * 16;
+            if (N % NTHREADS != 0 && c >= N) voff = 0x7fffffff;
+            r[i] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
         }
     }
     BPM_DEV void store(char* img, int tid) const {
@@ -659,7 +662,7 @@ int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S,
         const bpm_attn_problem& q = probs[i];
         AProb& p = g.p[i];
         if (q.B < 1 || q.H < 1 || q.T < 1 || q.S < 1 || q.dh < 1 || q.dh > q.dhp) return BPM_ERR_ARG;
-        if (q.T > (1 << 24) || q.S > (1 << 24)) return BPM_ERR_ARG;      // index arithmetic is 32-bit
+        if (q.T > (1 << 22) || q.S > (1 << 22)) return BPM_ERR_ARG;      // index arithmetic is 32-bit (rows * 512 B per head fits 31 bits)
         if (q.dhp != probs[0].dhp) return BPM_ERR_ARG;
         p.Q = (const char*)q.Q; p.K = (const char*)q.K; p.V = (const char*)q.V;
         p.O = (char*)q.O; p.ldo = q.ldo; p.lse = q.lse;
