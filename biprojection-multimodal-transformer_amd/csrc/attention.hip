@@ -54,27 +54,35 @@ constexpr int KT = 64;      // keys per tile (forward / dQ)
 #define BPM_ATTN_QT 64
 #endif
 #ifndef BPM_ATTN_DKV_W32
-#define BPM_ATTN_DKV_W32 3
+#define BPM_ATTN_DKV_W32 4
 #endif
 #ifndef BPM_ATTN_DKV_W64
-#define BPM_ATTN_DKV_W64 2
+#define BPM_ATTN_DKV_W64 3
+#endif
+#ifndef BPM_ATTN_DQ_W32
+#define BPM_ATTN_DQ_W32 5
+#endif
+#ifndef BPM_ATTN_DQ_W128
+#define BPM_ATTN_DQ_W128 3
 #endif
 #ifndef BPM_ATTN_DQ_W64
-#define BPM_ATTN_DQ_W64 3
+#define BPM_ATTN_DQ_W64 4
 #endif
 constexpr int QT = BPM_ATTN_QT;      // queries per tile (dK/dV): a multiple of 32
 
 // Waves per SIMD each kernel is compiled for (register budget 512 / waves), per kernel (0 forward, 1 dQ, 2 dK/dV),
 // compute type and padded head_dim: the largest occupancy at which the kernel does not spill inside its tile loop.
 // Measured on MI355X (tools/attn_lab.py, six encoders, B*H = 96 heads each, T = S = 512, masked), bf16: dQ at head_dim 64
-// 110 us at 4 waves (12 registers spilled) -> 98 at 3; dK/dV at head_dim 64 150 us at 3 waves (20 spilled) -> 144 at 2;
-// dK/dV at head_dim 25 127 us at 4 waves (25 spilled) -> 118 at 3.  The f32 (parity-mode) kernels need one wave fewer.
+// 110 us at 4 waves (12 registers spilled) -> 98 at 3.  Both backward kernels now compute one k-step of their second
+// product at a time (dQ: 112 registers at head_dim 64, 89 at 25, 166 at 128; dK/dV: 154 / 114 / 222), which fits one more
+// wave per SIMD without spills.  The f32 (parity-mode) kernels need
+// one wave fewer.
 template <typename CT>
 constexpr int attn_waves(int kernel, int dhp) {
     const bool bf = sizeof(CT) == 2;
-    if (dhp <= 32) return kernel == 0 ? (bf ? BPM_ATTN_WF : 4) : (kernel == 2 ? (bf ? BPM_ATTN_DKV_W32 : 3) : 4);
+    if (dhp <= 32) return kernel == 0 ? (bf ? BPM_ATTN_WF : 4) : (kernel == 2 ? (bf ? BPM_ATTN_DKV_W32 : 3) : (bf ? BPM_ATTN_DQ_W32 : 4));
     if (dhp <= 64) return kernel == 0 ? (bf ? 4 : 3) : kernel == 1 ? (bf ? BPM_ATTN_DQ_W64 : 3) : (bf ? BPM_ATTN_DKV_W64 : 2);
-    return kernel == 0 ? (bf ? 3 : 2) : BPM_ATTN_W128;
+    return kernel == 0 ? (bf ? 3 : 2) : (kernel == 1 && bf ? BPM_ATTN_DQ_W128 : BPM_ATTN_W128);
 }
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -438,49 +446,52 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, char* smem, const int bh, const i
         const int jb = kt * KT + 4 * g;
         const bool edge = kt * KT + KT > lim_min;
         const int rel = lim - jb;
-        f32x4 ds[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < C::NKS; ++s) {
-                s_ = Tr<CT>::mma(read_rowfrag<CT>(kimg, C::STRIDE, 16 * n, s, lane), qf[s], s_);
-                dp = Tr<CT>::mma(read_rowfrag<CT>(vimg, C::STRIDE, 16 * n, s, lane), dof[s], dp);
-            }
-            float dm[4] = {1.f, 1.f, 1.f, 1.f};
-            if (dropping) {
-                if (pair_ok) {
-                    bpm_drop_mult4(P.drop, drow + (uint32_t)(jb + 16 * n), dm[0], dm[1], dm[2], dm[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dm[r] = bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
-                }
-            }
-            f32x4 e4 = s_ * LOG2E + lse2;
-            if (edge) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) e4[r] = (16 * n + r < rel) ? e4[r] : -INFINITY;   // exp2(-inf) = 0: masked before the exponential
-            }
-            f32x4 p4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
-            const f32x4 dm4 = f32x4{dm[0], dm[1], dm[2], dm[3]};
-            ds[n] = p4 * (dp * dm4 - delta);
-        }
-        // dQ^T += K^T dS^T
-#if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
-#endif
+        // one k-step of the dQ product (32 keys in bf16, 16 in f32) at a time: its dS lives only until its MFMAs
+        constexpr int NPK = Tr<CT>::KSTEP / 16;
 #pragma unroll
         for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
-            const frag df = Tr<CT>::pack_rows(ds, ks);
+            f32x4 ds[NPK];
+#pragma unroll
+            for (int nn = 0; nn < NPK; ++nn) {
+                const int n = ks * NPK + nn;
+                f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < C::NKS; ++s) {
+                    s_ = Tr<CT>::mma(read_rowfrag<CT>(kimg, C::STRIDE, 16 * n, s, lane), qf[s], s_);
+                    dp = Tr<CT>::mma(read_rowfrag<CT>(vimg, C::STRIDE, 16 * n, s, lane), dof[s], dp);
+                }
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (dropping) {
+                    if (pair_ok) {
+                        bpm_drop_mult4(P.drop, drow + (uint32_t)(jb + 16 * n), dm[0], dm[1], dm[2], dm[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dm[r] = bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+                    }
+                }
+                f32x4 e4 = s_ * LOG2E + lse2;
+                if (edge) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e4[r] = (16 * n + r < rel) ? e4[r] : -INFINITY;   // exp2(-inf) = 0: masked before the exponential
+                }
+                f32x4 p4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
+                const f32x4 dm4 = f32x4{dm[0], dm[1], dm[2], dm[3]};
+                ds[nn] = p4 * (dp * dm4 - delta);
+            }
+            // dQ^T += K^T dS^T
+#if BPM_ATTN_SETPRIO
+            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
+#endif
+            const frag df = Tr<CT>::pack_rows(ds, 0);
 #pragma unroll
             for (int n = 0; n < C::ND; ++n)
                 dq[n] = Tr<CT>::mma(Tr<CT>::read_tr(kimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dq[n]);
-        }
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
+            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
 #endif
+        }
     }
     __syncthreads();                                   // every wave is done with the K / V images
     if (q0 < P.T)
@@ -575,51 +586,54 @@ BPM_DEV void attn_bwd_dkv_block(const AProb& P, char* smem, const int bh, const 
         __syncthreads();
         if (qt + 1 < qt_hi) stage(qt + 1);
         const bool edge = (qt * QT < ilo_max) || (qt * QT + QT > P.T);
-        constexpr int NU = QT / 16;
-        f32x4 pd[NU], ds[NU];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < C::NKS; ++s) {
-                s_ = Tr<CT>::mma(read_rowfrag<CT>(qimg, C::STRIDE, 16 * u, s, lane), kf[s], s_);
-                dp = Tr<CT>::mma(read_rowfrag<CT>(doimg, C::STRIDE, 16 * u, s, lane), vf[s], dp);
-            }
-            const f32x4 l4 = *(const f32x4*)(s_lse + 16 * u + 4 * g);
-            const f32x4 d4 = *(const f32x4*)(s_del + 16 * u + 4 * g);
-            const int ib = qt * QT + 16 * u + 4 * g;       // query of element r is ib + r
-            f32x4 e4 = s_ * LOG2E + l4;
-            if (edge) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) e4[r] = (ib + r >= ilo && ib + r < P.T) ? e4[r] : -INFINITY;
-            }
-            f32x4 p4, dm4 = f32x4{1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
-            if (dropping) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dm4[r] = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
-            }
-            pd[u] = p4 * dm4;
-            ds[u] = p4 * (dp * dm4 - d4);
-        }
-#if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
-#endif
+        // one k-step of the dV / dK products (32 queries in bf16, 16 in f32) at a time: its scores, probabilities and
+        // dS live only until its MFMAs (half the registers of doing the whole 64-query tile first)
+        constexpr int UPK = Tr<CT>::KSTEP / 16;
 #pragma unroll
         for (int ks = 0; ks < QT / Tr<CT>::KSTEP; ++ks) {
-            const frag pf = Tr<CT>::pack_rows(pd, ks);
-            const frag df = Tr<CT>::pack_rows(ds, ks);
+            f32x4 pd[UPK], ds[UPK];
+#pragma unroll
+            for (int uu = 0; uu < UPK; ++uu) {
+                const int u = ks * UPK + uu;
+                f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < C::NKS; ++s) {
+                    s_ = Tr<CT>::mma(read_rowfrag<CT>(qimg, C::STRIDE, 16 * u, s, lane), kf[s], s_);
+                    dp = Tr<CT>::mma(read_rowfrag<CT>(doimg, C::STRIDE, 16 * u, s, lane), vf[s], dp);
+                }
+                const f32x4 l4 = *(const f32x4*)(s_lse + 16 * u + 4 * g);
+                const f32x4 d4 = *(const f32x4*)(s_del + 16 * u + 4 * g);
+                const int ib = qt * QT + 16 * u + 4 * g;       // query of element r is ib + r
+                f32x4 e4 = s_ * LOG2E + l4;
+                if (edge) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e4[r] = (ib + r >= ilo && ib + r < P.T) ? e4[r] : -INFINITY;
+                }
+                f32x4 p4, dm4 = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
+                if (dropping) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dm4[r] = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
+                }
+                pd[uu] = p4 * dm4;
+                ds[uu] = p4 * (dp * dm4 - d4);
+            }
+#if BPM_ATTN_SETPRIO
+            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
+#endif
+            const frag pf = Tr<CT>::pack_rows(pd, 0);
+            const frag df = Tr<CT>::pack_rows(ds, 0);
 #pragma unroll
             for (int n = 0; n < C::ND; ++n) {
                 dv[n] = Tr<CT>::mma(Tr<CT>::read_tr(doimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, dv[n]);
                 dk[n] = Tr<CT>::mma(Tr<CT>::read_tr(qimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dk[n]);
             }
-        }
 #if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
+            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
 #endif
+        }
     }
     static_assert(2 * QT * C::STRIDE >= 4 * store_rows16_bytes<CT, DHP>(), "one transpose block per wave in the Q / dO images");
     __syncthreads();                                   // every wave is done with the Q / dO images
