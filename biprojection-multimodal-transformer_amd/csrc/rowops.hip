@@ -189,10 +189,32 @@ __global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc*
 // ---------------------------------------------------------------------------
 struct EmbP { const float* x; float* out; int T, B; int accumulate; int pos0, pstride; DropCfg drop; };
 
+// four consecutive channels per lane (d % 4 == 0, 16-byte aligned tensors, < 2^32 elements): 32-bit index arithmetic, one
+// dropout hash per quad, 16-byte accesses; the element-wise loops below are the general path
+BPM_DEV bool emb_wide(const EmbP& P, const float* table, int d, size_t total) {
+    return (d & 3) == 0 && total < (1ull << 32) && (((uintptr_t)P.x | (uintptr_t)P.out | (uintptr_t)table) & 15) == 0;
+}
+
 __global__ void embed_pos_fwd_kernel(const Grp<EmbP> grp, const float* __restrict__ table, int d, float scale) {
     unsigned bid = blockIdx.x, nblk;
     const EmbP& P = pick(grp, bid, nblk);
     const size_t total = (size_t)P.T * P.B * d;
+    if (emb_wide(P, table, d, total)) {
+        const uint32_t total4 = (uint32_t)(total >> 2), ud = (uint32_t)d;
+        for (uint32_t q = bid * NT + threadIdx.x; q < total4; q += nblk * NT) {
+            const uint32_t i = 4u * q, row = i / ud, c = i - row * ud;
+            const int t = (int)(row / (uint32_t)P.B);
+            const int pos = (P.x[(size_t)row * ud] != 0.f) ? P.pos0 + t * P.pstride + 1 : 0;
+            f32x4 v = scale * *(const f32x4*)(P.x + i) + *(const f32x4*)(table + (size_t)pos * ud + c);
+            if (P.drop.thresh != 0) {
+                float d0, d1, d2, d3;
+                bpm_drop_mult4(P.drop, i, d0, d1, d2, d3);
+                v *= f32x4{d0, d1, d2, d3};
+            }
+            *(f32x4*)(P.out + i) = v;
+        }
+        return;
+    }
     for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
         const int c = (int)(i % d);
         const size_t row = i / d;
@@ -206,6 +228,21 @@ __global__ void embed_pos_bwd_kernel(const Grp<EmbP> grp, int d, float scale) {
     unsigned bid = blockIdx.x, nblk;
     const EmbP& P = pick(grp, bid, nblk);      // x = dy, out = dx
     const size_t total = (size_t)P.T * P.B * d;
+    if (emb_wide(P, nullptr, d, total)) {
+        const uint32_t total4 = (uint32_t)(total >> 2);
+        for (uint32_t q = bid * NT + threadIdx.x; q < total4; q += nblk * NT) {
+            const uint32_t i = 4u * q;
+            f32x4 v = scale * *(const f32x4*)(P.x + i);
+            if (P.drop.thresh != 0) {
+                float d0, d1, d2, d3;
+                bpm_drop_mult4(P.drop, i, d0, d1, d2, d3);
+                v *= f32x4{d0, d1, d2, d3};
+            }
+            f32x4* o = (f32x4*)(P.out + i);
+            *o = P.accumulate ? *o + v : v;
+        }
+        return;
+    }
     for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
         const float v = scale * P.x[i] * bpm_drop_mult(P.drop, (uint32_t)i);
         P.out[i] = P.accumulate ? P.out[i] + v : v;
