@@ -405,7 +405,12 @@ class EncoderGroupPlan:
             b["dyf"] = [z(R, self.ld, dt=ct) for _ in range(3)]
             b["dq"], b["dk"], b["dv"] = two(R, self.ld), two(Rk, self.ld), two(Rk, self.ld)
             if cfg.biprojection:
-                b["dy0"], b["dqs"], b["dks"], b["dvs"] = two(R, self.ld), two(R, self.ld), two(R, self.ld), two(R, self.ld)
+                b["dy0"] = two(R, self.ld)
+                # dQ | dK | dV of the self-attention half side by side in one [R, 3 ld] buffer: without column padding
+                # (ld == d) that is the [R, 3d] operand of ONE d(xn) = [dq dk dv] in_proj_weight product (K = 3d) instead
+                # of three K = d launches accumulating into the same output
+                b["dqkvs"] = two(R, 3 * self.ld)
+                b["dqs"], b["dks"], b["dvs"] = ([t[:, w * self.ld:(w + 1) * self.ld] for t in b["dqkvs"]] for w in range(3))
             # read by the side-stream dK/dV pass of the cross attention: by layer parity like dq/dk/dv
             b["dao"] = [z(B, H, e.T, self.dhp, dt=ct) for _ in range(2)]
             b["delta"] = [z(B, H, e.T) for _ in range(2)]
@@ -747,16 +752,19 @@ class EncoderGroupPlan:
                                                      heads=(B, H, e.T, dh, dhp)))
                     s_att0.append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H, e.T, e.T,
                                                    dh, dhp, self._mask_off(e.T, e.T), dO=b["dao0"], delta=b["delta0"], dQ=dqs,
-                                                   lddq=ld, dK=dks, lddk=ld, dV=dvs, lddv=ld, dq_scale=self.scale,
+                                                   lddq=3 * ld, dK=dks, lddk=3 * ld, dV=dvs, lddv=3 * ld, dq_scale=self.scale,
                                                    drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
                     for w, src in ((0, dqs), (1, dks), (2, dvs)):
-                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, ld, ld, d, flags=F_ACCUM,
+                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, 3 * ld, ld, d, flags=F_ACCUM,
                                                       colsum_a=st.gptr(ipb_g, w * d)))
                     # d(xn) = dq Wq + dk Wk + dv Wv: three launches (plain store, then two +=) -- one owner per
                     # output tile in each launch, no atomics (per-lane-scattered float atomics run ~17x below store rate)
-                    s_dg0a.append(ops.gemm_problem(dqs, st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
-                    s_dg0b.append(ops.gemm_problem(dks, st.sptr(ipw, d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
-                    s_dg0c.append(ops.gemm_problem(dvs, st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, ld, ld, d, flags=F_ACCUM))
+                    if ld == d:                                   # one product over K = 3d (see the dqkvs buffer)
+                        s_dg0a.append(ops.gemm_problem(b["dqkvs"][par], st.sptr(ipw, 0), b["dxn"], R, d, 3 * d, 3 * ld, ld, d))
+                    else:
+                        s_dg0a.append(ops.gemm_problem(dqs, st.sptr(ipw, 0), b["dxn"], R, d, d, 3 * ld, ld, d))
+                        s_dg0b.append(ops.gemm_problem(dks, st.sptr(ipw, d * ld), b["dxn"], R, d, d, 3 * ld, ld, d, flags=F_ACCUM))
+                        s_dg0c.append(ops.gemm_problem(dvs, st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, 3 * ld, ld, d, flags=F_ACCUM))
                     s_ln0.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R,
                                                 dy=b["dxn"], ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"),
                                                 dbeta=GP("layer_norms.0.bias"), **nxt))
@@ -783,10 +791,9 @@ class EncoderGroupPlan:
                           self._gemm(GEMM_NN, s_dgout0),
                           (ops.attn_bwd, self.dtype, A(AttnProblem, s_att0)),
                           (SIDE, self._gemm(GEMM_TN, s_wg0, background=True)),
-                          self._gemm(GEMM_NN, s_dg0a),
-                          self._gemm(GEMM_NN, s_dg0b),
-                          self._gemm(GEMM_NN, s_dg0c),
-                          (ops.ln_bwd, A(LnProblem, s_ln0), d)]
+                          self._gemm(GEMM_NN, s_dg0a)] + \
+                         ([self._gemm(GEMM_NN, s_dg0b), self._gemm(GEMM_NN, s_dg0c)] if s_dg0b else []) + \
+                         [(ops.ln_bwd, A(LnProblem, s_ln0), d)]
             # folded K/V gradients of this layer -> in_proj / LayerNorm parameter gradients; with it every gradient of
             # layer i is final once the side stream reaches MARK i and the main stream this point (all-reduce hook)
             steps += [(SIDE, (ops.unfold_grads,) + self._unfold[i]), (MARK, i)]
