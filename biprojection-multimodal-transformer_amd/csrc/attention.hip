@@ -287,8 +287,11 @@ BPM_DEV void attn_fwd_block(const AProb& P, char* smem, const int bh, const int 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[n][r] = (16 * n + r < rel) ? st[n][r] : -INFINITY;
         }
-        float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])), fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])), fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
+        // 3-input maxima (v_max3_f32): two chains of four instead of a tree of fifteen 2-input ones
+        auto max3 = [](float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); };
+        float mx = max3(max3(max3(max3(st[0][0], st[0][1], st[0][2]), st[0][3], st[1][0]), st[1][1], st[1][2]), st[1][3], st[2][0]);
+        float my = max3(max3(max3(st[2][1], st[2][2], st[2][3]), st[3][0], st[3][1]), st[3][2], st[3][3]);
+        mx = fmaxf(mx, my);
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
