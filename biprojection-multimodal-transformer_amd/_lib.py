@@ -28,6 +28,7 @@ OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
 F_ACCUM, F_RELU, F_ATOMIC, F_KPAD, F_BACKGROUND = 1, 2, 4, 8, 16     # F_KPAD = BPM_GEMM_KPAD_ZERO
 LN_OUT_F32 = 2
 MAX_GROUP = 18
+GEMM_MAX_GROUP = 24
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

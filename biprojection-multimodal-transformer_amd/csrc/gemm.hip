@@ -85,29 +85,30 @@ constexpr int TN = BN / WN / 16;          // 2 along n
 #define BPM_KS_WGRAD 2
 #endif
 constexpr int KS_FWD = BPM_KS_FWD, KS_WGRAD = BPM_KS_WGRAD;
-struct Prob {
+struct Prob {                              // 168 bytes: 24 of them (+ the header) are one 4 KB kernel argument
     const char* X; const char* Y; char* C;
     int M, N, K;
     int ldx, ldy, ldc;
     const float* bias_n; const float* bias_m;
-    const float* resid; int ldr;
-    const char* gate; int ldg; float gate_scale;
+    const float* resid; const char* gate;
+    int ldr, ldg; float gate_scale;
     float alpha;
-    DropCfg drop;
     float* colsum;
     float* colsum_x;      // TN: [M] += sum_k X[k, m]
+    DropCfg drop;
     int flags;
     int out_kind;
     int hB, hH, hT, hdh, hdhp;
     int tile0, tiles_m, tiles_n, splitk;
-    int splitk_is_one;                     // no split-K
 };
+static_assert(sizeof(Prob) == 168, "Prob layout");
 
 struct Group {
     int nprob;
     int total_tiles;
-    Prob p[BPM_MAX_GROUP];
+    Prob p[BPM_GEMM_MAX_GROUP];
 };
+static_assert(sizeof(Group) + 16 <= 4096, "the problem table travels as a kernel argument (4 KB)");
 
 BPM_DEV int swz4(int row) { return (-(row >> 2)) & 3; }
 
@@ -247,7 +248,7 @@ BPM_DEV void flush_colsum(const Prob& P, float (&csum)[4], int nb, int r) {
 BPM_DEV bool epi_fast_ok(const Prob& P) {
     const uintptr_t al = (uintptr_t)P.bias_n | (uintptr_t)P.resid | (uintptr_t)P.C | (uintptr_t)P.gate;
     return (P.N & 3) == 0 && (al & 15) == 0 && ((P.ldr | P.ldc | P.ldg) & 3) == 0 && !P.bias_m &&
-           !(P.flags & BPM_GEMM_ATOMIC) && P.splitk_is_one && !(P.resid && (P.flags & BPM_GEMM_ACCUM));
+           !(P.flags & BPM_GEMM_ATOMIC) && P.splitk == 1 && !(P.resid && (P.flags & BPM_GEMM_ACCUM));
 }
 
 struct EpiRow {            // per output row m: everything that does not depend on the column
@@ -825,7 +826,7 @@ extern "C" int bpm_debug_trace(unsigned long long* out, int nblocks) {
 #endif
 
 extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs, int nprob, uint64_t seed, void* stream) {
-    if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
+    if (nprob < 1 || nprob > BPM_GEMM_MAX_GROUP || !probs) return BPM_ERR_ARG;
     if (variant != BPM_GEMM_NT && variant != BPM_GEMM_NN && variant != BPM_GEMM_TN) return BPM_ERR_ARG;
     const int sz = dtype == BPM_BF16 ? 2 : 4;
     const bool xk = variant != BPM_GEMM_TN, yk = variant == BPM_GEMM_NT;
@@ -850,6 +851,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     int dma = -1;
     if (dtype == BPM_BF16 && fast && g_force_dma != -2) {
         bool legal = true, big = true;
+        long tiles_tn = 0;
         for (int i = 0; i < nprob && legal; ++i) {
             const bpm_gemm_problem& q = probs[i];
             const long kceil = ((long)q.K + DK - 1) / DK * DK;
@@ -859,9 +861,13 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
             legal = legal && (q.N & 3) == 0 && (al & 15) == 0 && ((q.ldr | q.ldc | q.ldg) & 3) == 0 && !q.bias_m &&
                     !(q.resid && (q.flags & BPM_GEMM_ACCUM));
             const long tm = (q.M + 255) / 256, tn = (q.N + 255) / 256;
-            big = big && q.M >= 256 && q.N >= 256 && q.K >= 256 && (variant != BPM_GEMM_TN || tm * tn >= 24) &&
+            big = big && q.M >= 256 && q.N >= 256 && q.K >= 256 &&
                   (double)q.M * q.N >= 0.8 * (double)(tm * 256) * (double)(tn * 256);
+            tiles_tn += tm * tn;
         }
+        // weight gradients: one 256 x 256 tile per CU only pays when most CUs get one (the six encoders' q / k / v / out
+        // gradients together are 216 tiles: 235 us on the 128 x 64 kernel in two launches, one round here)
+        if (variant == BPM_GEMM_TN && tiles_tn * 4 < num_cus() * 3) big = false;
         if (legal && g_force_dma >= 0) dma = g_force_dma == CFG_TALL && variant == BPM_GEMM_TN ? -1 : g_force_dma;
         else if (legal && big) {
             dma = variant == BPM_GEMM_TN ? 2 : 3;
@@ -923,7 +929,6 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         p.tiles_m = (q.M + bm_tile - 1) / bm_tile;
         p.tiles_n = ntiles;
         p.splitk = q.splitk > 1 ? q.splitk : 1;
-        p.splitk_is_one = p.splitk == 1;
         if (p.splitk > 1 && !((q.flags & BPM_GEMM_ATOMIC) && q.out_kind == BPM_OUT_F32)) return BPM_ERR_ARG;
         tile += p.tiles_m * p.tiles_n * p.splitk;
     }

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, MAX_GROUP, OUT_CT,
+from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, GEMM_MAX_GROUP, MAX_GROUP, OUT_CT,
                    OUT_F32, OUT_HEADS, AttnProblem, CastProblem, EmbedProblem, GemmProblem, GmuProblem,
                    LnProblem, PackProblem)
 
@@ -50,10 +50,10 @@ def array(cls, probs: Sequence):
     return (cls * len(probs))(*probs)
 
 
-def _chunks(arr, cls, n):
+def _chunks(arr, cls, n, limit=MAX_GROUP):
     n = len(arr) if n is None else n
-    for i in range(0, n, MAX_GROUP):
-        k = min(MAX_GROUP, n - i)
+    for i in range(0, n, limit):
+        k = min(limit, n - i)
         yield C.cast(C.byref(arr, i * C.sizeof(cls)), C.POINTER(cls)), k
 
 
@@ -88,7 +88,7 @@ def gemm_problem(A, B, Cc, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
 def gemm_grouped(dtype: int, variant: int, probs, seed: int = 0, n: Optional[int] = None) -> None:
     arr = _as_array(GemmProblem, probs)
     L, s = _lib.lib(), _stream()
-    for sub, k in _chunks(arr, GemmProblem, n):
+    for sub, k in _chunks(arr, GemmProblem, n, GEMM_MAX_GROUP):
         _lib.check(L.bpm_gemm_grouped(dtype, variant, sub, k, seed, s), "bpm_gemm_grouped")
 
 

@@ -34,6 +34,7 @@ extern "C" {
 
 #define BPM_ABI_VERSION 1
 #define BPM_MAX_GROUP 18 /* problems per grouped launch (6 encoders of a level x 3 projections) */
+#define BPM_GEMM_MAX_GROUP 24 /* bpm_gemm_grouped alone: 6 encoders x (q, k, v, out) weight gradients in one launch */
 
 enum { BPM_F32 = 0, BPM_BF16 = 1 };
 enum { BPM_ERR_ARG = -1, BPM_ERR_ALIGN = -2 };

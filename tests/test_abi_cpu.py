@@ -30,6 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, name), name
     assert lib.bpm_version() == int(re.search(r"#define BPM_ABI_VERSION (\d+)", HEADER).group(1))
     assert _lib.MAX_GROUP == int(re.search(r"#define BPM_MAX_GROUP (\d+)", HEADER).group(1))
+    assert _lib.GEMM_MAX_GROUP == int(re.search(r"#define BPM_GEMM_MAX_GROUP (\d+)", HEADER).group(1))
 
 
 def _c_fields(struct_name):
