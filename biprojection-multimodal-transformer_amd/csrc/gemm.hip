@@ -865,9 +865,9 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
                   (double)q.M * q.N >= 0.8 * (double)(tm * 256) * (double)(tn * 256);
             tiles_tn += tm * tn;
         }
-        // weight gradients: one 256 x 256 tile per CU only pays when most CUs get one (the six encoders' q / k / v / out
-        // gradients together are 216 tiles: 235 us on the 128 x 64 kernel in two launches, one round here)
-        if (variant == BPM_GEMM_TN && tiles_tn * 4 < num_cus() * 3) big = false;
+        // weight gradients: one 256 x 256 tile per CU only pays when most CUs get one (measured, 768 x 768 x 4096 problems
+        // with bias column sums: 24 problems = 216 tiles 227 -> 181 us, 18 = 162 tiles 169 -> 156, 12 = 108 tiles 114 -> ~150)
+        if (variant == BPM_GEMM_TN && tiles_tn * 8 < num_cus() * 5) big = false;
         if (legal && g_force_dma >= 0) dma = g_force_dma == CFG_TALL && variant == BPM_GEMM_TN ? -1 : g_force_dma;
         else if (legal && big) {
             dma = variant == BPM_GEMM_TN ? 2 : 3;

@@ -269,12 +269,16 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < TMW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    [[maybe_unused]] f32x4 xs[TMW];
+    // bias gradient beside a weight gradient: column sums of X (see the tiled kernel), in the tiles of column block 0.  The
+    // TMW m tiles of a wave row are dealt over its WND waves (XB each): one wave doing all of them is 25 % more MFMAs for
+    // that wave, and with a barrier per stage the whole workgroup -- and, one tile per CU, the launch -- waits for it.
+    constexpr int XB = (TMW + WND - 1) / WND;
+    [[maybe_unused]] f32x4 xs[XB];
     [[maybe_unused]] bool do_xs = false;
-    if constexpr (XS) {                    // bias gradient beside a weight gradient: column sums of X (see the tiled kernel)
-        do_xs = P.colsum_x != nullptr && n0 == 0 && wn == 0;
+    if constexpr (XS) {
+        do_xs = P.colsum_x != nullptr && n0 == 0;
 #pragma unroll
-        for (int b = 0; b < TMW; ++b) xs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < XB; ++b) xs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
 #pragma unroll
@@ -307,7 +311,8 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
 #pragma unroll
                     for (int j = 0; j < 8; ++j) one[j] = (bf16_t)1.0f;
 #pragma unroll
-                    for (int b = 0; b < TMW; ++b) xs[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fx[b], xs[b], 0, 0, 0);
+                    for (int b = 0; b < TMW; ++b)
+                        if (b / XB == wn) xs[b % XB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fx[b], xs[b % XB], 0, 0, 0);
                 }
             }
             if (more && !(BPM_DMA_ABLATE & 2)) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks>{});
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
 #pragma unroll
             for (int b = 0; b < TMW; ++b) {
                 const int m = mw + 16 * b + r;
-                if (m < P.M) P.colsum_x[m] += xs[b][0];
+                if (b / XB == wn && m < P.M) P.colsum_x[m] += xs[b % XB][0];
             }
         }
     }
