@@ -563,14 +563,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
 #pragma unroll
         for (int b = 0; b < TMT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // TN only: column sums of X (bias gradient beside a weight gradient) in the workgroups of the first N tile, by the
-    // waves of the first wave column: one MFMA per X fragment against an operand of ones
-    [[maybe_unused]] f32x4 xs[TMT];
+    // TN only: column sums of X (bias gradient beside a weight gradient) in the workgroups of the first N tile: one MFMA
+    // per X fragment against an operand of ones, the m tiles of a wave row dealt over its WN waves (one wave doing all of
+    // them has 50 % more MFMAs than the rest and the workgroup's barriers make everyone wait for it)
+    constexpr int XBT = (TMT + WN - 1) / WN;
+    [[maybe_unused]] f32x4 xs[XBT];
     [[maybe_unused]] bool do_xs = false;
     if constexpr (!XK && !YK) {
-        do_xs = P.colsum_x != nullptr && n0 == 0 && wn == 0;       // wave-uniform
+        do_xs = P.colsum_x != nullptr && n0 == 0;                  // wave-uniform
 #pragma unroll
-        for (int b = 0; b < TMT; ++b) xs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < XBT; ++b) xs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     auto compute = [&](const char* ix) {
         const char* iy = ix + SX::IMG_BYTES;
@@ -585,7 +587,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
 #pragma unroll
                     for (int j = 0; j < Tr<CT>::EPC; ++j) one[j] = Tr<CT>::from_f(1.0f);
 #pragma unroll
-                    for (int b = 0; b < TMT; ++b) xs[b] = Tr<CT>::mma(one, fx[b], xs[b]);
+                    for (int b = 0; b < TMT; ++b)
+                        if (b / XBT == wn) xs[b % XBT] = Tr<CT>::mma(one, fx[b], xs[b % XBT]);
                 }
             }
 #pragma unroll
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
 #pragma unroll
             for (int b = 0; b < TMT; ++b) {
                 const int m = m0 + wm * (BMT / WM) + 16 * b + r;
-                if (m < P.M) P.colsum_x[m] += xs[b][0];
+                if (b / XBT == wn && m < P.M) P.colsum_x[m] += xs[b % XBT][0];
             }
         }
     }
