@@ -409,8 +409,10 @@ class EncoderGroupPlan:
                 # dQ | dK | dV of the self-attention half side by side in one [R, 3 ld] buffer: without column padding
                 # (ld == d) that is the [R, 3d] operand of ONE d(xn) = [dq dk dv] in_proj_weight product (K = 3d) instead
                 # of three K = d launches accumulating into the same output
-                b["dqkvs"] = two(R, 3 * self.ld)
-                b["dqs"], b["dks"], b["dvs"] = ([t[:, w * self.ld:(w + 1) * self.ld] for t in b["dqkvs"]] for w in range(3))
+                # (one spare row: the bounded loaders size their descriptors rows x ld from each VIEW's first element, so
+                # the dK / dV views' ranges reach up to 2 ld elements past row R - 1)
+                b["dqkvs"] = two(R + 1, 3 * self.ld)
+                b["dqs"], b["dks"], b["dvs"] = ([t[:R, w * self.ld:(w + 1) * self.ld] for t in b["dqkvs"]] for w in range(3))
             # read by the side-stream dK/dV pass of the cross attention: by layer parity like dq/dk/dv
             b["dao"] = [z(B, H, e.T, self.dhp, dt=ct) for _ in range(2)]
             b["delta"] = [z(B, H, e.T) for _ in range(2)]
