@@ -31,18 +31,38 @@ MAX_GROUP = 18
 GEMM_MAX_GROUP = 24
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 every csrc/*.hip into one shared library (in-tree)."""
+def build(force: bool = False, verbose: bool = False, out: str | None = None, flags: tuple = (), objdir: str | None = None) -> str:
+    """hipcc --offload-arch=gfx950: every csrc/*.hip to an object file (in parallel; only the stale ones), then one shared
+    library in-tree.  `out` / `flags` / `objdir`: variant builds for the lab tools (e.g. -DBPM_DMA_ABLATE=4)."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = out or LIB_PATH
+    objdir = objdir or os.path.join(_HERE, "..", "build", "obj" + ("_" + str(abs(hash(tuple(flags))) % 100000) if flags else ""))
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(_HERE, "..", "include", "bpmult_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(_HERE, "..", "include", "bpmult_hip.h")]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in srcs + hdrs):
+        return out
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + list(flags)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
+            return obj
+        cmd = common + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 class GemmProblem(C.Structure):
@@ -188,6 +208,7 @@ SIGNATURES = {
     "bpm_stream_priority_range": [C.POINTER(_I), C.POINTER(_I)],
     "bpm_prof_enable": [C.c_uint],
     "bpm_prof_collect": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)],
+    "bpm_prof_collect2": [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)],
 }
 
 _lib = None

@@ -719,6 +719,19 @@ double useful_pair_flops(const bpm_attn_problem* probs, int nprob) {
     return tot;
 }
 
+// algorithmic HBM bytes of one launch: every tensor it must read or write once (which: 0 forward, 1 dQ + delta, 2 dK / dV)
+double attn_bytes(const bpm_attn_problem* probs, int nprob, int sz, int which) {
+    double tot = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const bpm_attn_problem& q = probs[i];
+        const double bh = (double)q.B * q.H, qe = bh * q.T * q.dh * sz, ke = bh * q.S * q.dh * sz, st = bh * q.T * 4;
+        if (which == 0) tot += 2 * qe + 2 * ke + st;                 // Q, K, V in; O, lse out
+        else if (which == 1) tot += 4 * qe + 2 * ke + 2 * st;        // Q, K, V, O, dO, lse in; dQ, delta out
+        else tot += 2 * qe + 4 * ke + 2 * st;                        // Q, K, V, dO, lse, delta in; dK, dV out
+    }
+    return tot;
+}
+
 template <typename CT>
 int dispatch(int which, int dhp, const AGroup& g, int total, hipStream_t s) {
     dim3 grid(total), block(NTHREADS);
@@ -755,7 +768,7 @@ extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob,
     for (int i = 0; i < nprob; ++i)
         if (!probs[i].Q || !probs[i].K || !probs[i].V || !probs[i].O || !probs[i].lse) return BPM_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    BpmProfScope prof(BPM_K_ATTN_FWD, s, 4.0 * useful_pair_flops(probs, nprob));
+    BpmProfScope prof(BPM_K_ATTN_FWD, s, 4.0 * useful_pair_flops(probs, nprob), attn_bytes(probs, nprob, dtype == BPM_BF16 ? 2 : 4, 0));
     return dtype == BPM_BF16 ? dispatch<bf16_t>(0, probs[0].dhp, g, total, s) : dispatch<float>(0, probs[0].dhp, g, total, s);
 }
 
@@ -776,14 +789,14 @@ static int attn_bwd_parts(int dtype, const bpm_attn_problem* probs, int nprob, u
     // algorithmic backward = dP, dQ (first kernel) + dV, dK (second): 4 * pairs * dh each; recomputing S is overhead
     const double w = 4.0 * useful_pair_flops(probs, nprob);
     if (parts & 1) {
-        BpmProfScope prof(BPM_K_ATTN_BWD_DQ, s, w);
+        BpmProfScope prof(BPM_K_ATTN_BWD_DQ, s, w, attn_bytes(probs, nprob, dtype == BPM_BF16 ? 2 : 4, 1));
         rc = dtype == BPM_BF16 ? dispatch<bf16_t>(1, probs[0].dhp, g, total, s) : dispatch<float>(1, probs[0].dhp, g, total, s);
         if (rc) return rc;
     }
     if (parts & 2) {
         rc = fill(g, probs, nprob, 1, seed, &total, 2);
         if (rc) return rc;
-        BpmProfScope prof(BPM_K_ATTN_BWD_DKV, s, w);
+        BpmProfScope prof(BPM_K_ATTN_BWD_DKV, s, w, attn_bytes(probs, nprob, dtype == BPM_BF16 ? 2 : 4, 2));
         rc = dtype == BPM_BF16 ? dispatch<bf16_t>(2, probs[0].dhp, g, total, s) : dispatch<float>(2, probs[0].dhp, g, total, s);
     }
     return rc;

@@ -613,8 +613,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
     [[maybe_unused]] int vx[SX::PER_THREAD], vy[SY::PER_THREAD];
     [[maybe_unused]] int stepx = 0, stepy = 0;
     if constexpr (FAST) {
-        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)Xp, 0, (XK ? Mb : Kb) * ldx * (int)sizeof(CT), 0x00020000);
-        rsy = __builtin_amdgcn_make_buffer_rsrc((void*)Yp, 0, (YK ? Nb : Kb) * ldy * (int)sizeof(CT), 0x00020000);
+        // tight descriptors (see desc_bytes in gemm_dma.h): whole k stages of a k-contiguous row, whole chunks of a k-strided one
+        constexpr int E = Tr<CT>::EPC;
+        const int kceil = (Kb + BK - 1) / BK * BK;
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)Xp, 0, ((XK ? Mb : Kb) - 1) * ldx * (int)sizeof(CT) + min(XK ? kceil : (Mb + E - 1) / E * E, ldx) * (int)sizeof(CT), 0x00020000);
+        rsy = __builtin_amdgcn_make_buffer_rsrc((void*)Yp, 0, ((YK ? Nb : Kb) - 1) * ldy * (int)sizeof(CT) + min(YK ? kceil : (Nb + E - 1) / E * E, ldy) * (int)sizeof(CT), 0x00020000);
         SX::voffsets(ldx, m0, tid, vx);
         SY::voffsets(ldy, n0, tid, vy);
         stepx = SX::stage_step(ldx);
@@ -937,9 +940,18 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     }
     g.total_tiles = tile;
     hipStream_t s = (hipStream_t)stream;
-    double flops = 0;
-    for (int i = 0; i < nprob; ++i) flops += 2.0 * probs[i].M * (double)probs[i].N * probs[i].K;
-    BpmProfScope prof(BPM_K_GEMM_NT + variant, s, flops);
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const bpm_gemm_problem& q = probs[i];
+        flops += 2.0 * q.M * (double)q.N * q.K;
+        // algorithmic HBM bytes: each operand once, the output once, each side operand of the epilogue once
+        const double mn = (double)q.M * q.N;
+        bytes += ((double)q.M + q.N) * q.K * sz + mn * (q.out_kind == BPM_OUT_F32 ? 4 : sz);
+        if (q.resid) bytes += mn * 4;
+        if (q.gate) bytes += mn * sz;
+        if (q.out_kind == BPM_OUT_F32 && (q.flags & BPM_GEMM_ACCUM)) bytes += mn * 4;
+    }
+    BpmProfScope prof(BPM_K_GEMM_NT + variant, s, flops, bytes);
     if (dma >= 0) return launch_dma(dma, variant, g, s);
     return dtype == BPM_BF16 ? launch<bf16_t>(variant, fast, bm_tile == 64, g, s)
                              : launch<float>(variant, fast, bm_tile == 64, g, s);

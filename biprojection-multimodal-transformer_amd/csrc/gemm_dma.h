@@ -37,6 +37,8 @@
 constexpr int DK = 64;                     // k elements per stage
 constexpr int DROW = 128;                  // bytes of k per row-image row
 
+BPM_DEV int desc_bytes(int rows, int ld, int width, int sz) { return ((rows - 1) * ld + min(width, ld)) * sz; }
+
 BPM_DEV int dma_row_off(int row, int c) { return row * DROW + ((c ^ ((row >> 1) & 7)) << 4); }
 BPM_DEV int dma_col_off(int krow, int ch) { return krow * 256 + ((ch ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4); }
 
@@ -250,8 +252,11 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     const int m0 = (bid / P.tiles_n) * BMD, n0 = (bid % P.tiles_n) * BND;
     const int nkt = (P.K + DK - 1) / DK;
 
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, (XK ? P.M : P.K) * P.ldx * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, (YK ? P.N : P.K) * P.ldy * 2, 0x00020000);
+    // descriptor = exactly the bytes the operand owns: (rows - 1) leading dimensions plus the last row's width (whole k
+    // stages of a k-contiguous row, whole 16-byte chunks of a k-strided one) -- an operand that is a COLUMN VIEW of a wider
+    // buffer then never reads past the parent's last row (rows * ld from the view's first element would)
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, desc_bytes(XK ? P.M : P.K, P.ldx, XK ? nkt * DK : (P.M + 7) & ~7, 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, desc_bytes(YK ? P.N : P.K, P.ldy, YK ? nkt * DK : (P.N + 7) & ~7, 2), 0x00020000);
     const int vx = SX::voffset(P.ldx, m0, wave, lane), vy = SY::voffset(P.ldy, n0, wave, lane);
     const int stepx = SX::stage_step(P.ldx), stepy = SY::stage_step(P.ldy);
     const int ldx = P.ldx, ldy = P.ldy;

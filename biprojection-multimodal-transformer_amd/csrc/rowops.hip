@@ -957,6 +957,20 @@ extern "C" int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* q, int n, int d, u
             sums = sums || q[i].dgamma || (q[i].cast && q[i].cast_colsum);
             if (((uintptr_t)q[i].dgamma | (uintptr_t)q[i].dbeta | (uintptr_t)q[i].cast_colsum) & 15) ws = nullptr;   // 16-byte row sums
         }
+        // the last block of a problem adds its partial rows to dgamma / dbeta / cast_colsum with a plain read-modify-write:
+        // exact only while no other problem of this launch owns the same row (and, host contract, no other stream
+        // accumulates into it while this launch runs: include/bpmult_hip.h).  Shared rows go out as float atomics.
+        if (ws && sums) {
+            const float* rows[3 * BPM_MAX_GROUP];
+            int nr = 0;
+            for (int i = 0; i < n; ++i) {
+                if (q[i].dgamma) { rows[nr++] = q[i].dgamma; rows[nr++] = q[i].dbeta; }
+                if (q[i].cast && q[i].cast_colsum) rows[nr++] = q[i].cast_colsum;
+            }
+            for (int a = 0; a < nr && ws; ++a)
+                for (int b = a + 1; b < nr; ++b)
+                    if (rows[a] && rows[a] == rows[b]) { ws = nullptr; break; }
+        }
         float* w = nullptr;
         if (ws && sums) {
             if (((uintptr_t)ws & 15) || ws_bytes < ((size_t)g.blk0[n] * 3 * d + LN_WS_HEAD) * sizeof(float)) return BPM_ERR_ARG;

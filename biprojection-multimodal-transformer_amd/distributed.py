@@ -21,37 +21,55 @@ reduced as one flattened message at the end.
   flat buffer and hands 1/world to the optimizer, whose kernel multiplies the
   gradient as it reads it (`bpm_adam_step(grad_scale)`).  Without an optimizer
   the buffer is scaled in place so that `.grad` holds the mean.
-* `compress="bf16"` (opt-in) exchanges bf16 copies of the slices: half the
-  bytes on the xGMI ring (hidden 768, 4-modal: 1.85 GB of fp32 gradients are
-  ~21 ms of ring all-reduce) for one rounding of each
-  rank's summand; the sum is accumulated by RCCL in bf16.
+* `compress`: "auto" (default) exchanges bf16 copies of the slices when the
+  fp32 gradient buffer is larger than AUTO_BF16_BYTES (1 GiB): a ring all-reduce
+  moves 2 (w-1)/w x bytes over ONE xGMI link per GPU (~153 GB/s, SURVEY.md
+  section 5), so the headline model's 2.7 GB of fp32 gradients are ~31 ms of
+  ring time against a 30 ms step -- nothing to hide them behind -- while bf16
+  halves that for one rounding of each rank's summand (RCCL accumulates the sum
+  in bf16).  hidden 300 (0.44 GB, ~5 ms) stays fp32.  "none" forces fp32,
+  "bf16" forces bf16.
 """
 from __future__ import annotations
 
+import collections
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
 
+AUTO_BF16_BYTES = 1 << 30
+
+
 class GradSync:
-    def __init__(self, model, bucket_bytes: int = 128 << 20, process_group=None, optimizer=None, compress: str = "none"):
-        if compress not in ("none", "bf16"):
-            raise ValueError("compress must be 'none' or 'bf16'")
+    def __init__(self, model, bucket_bytes: int = 128 << 20, process_group=None, optimizer=None, compress: str = "auto"):
+        if compress not in ("auto", "none", "bf16"):
+            raise ValueError("compress must be 'auto', 'none' or 'bf16'")
         self.model, self.pg = model, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket = bucket_bytes // 4
         self.optimizer = optimizer
-        self.compress = compress
+        self.compress_arg = compress
+        self.compress = compress if compress != "auto" else None      # resolved at the first exchange (needs the store)
         self.comm: Optional[torch.cuda.Stream] = None
         self.handles: List = []
         self._half: List = []        # (bf16 staging buffer, fp32 slice) pairs of the step in flight
         self.active = True           # set False on non-final gradient-accumulation micro-steps
-        self._exposed: List = []     # (event before waiting for the exchange, event after) per step
+        # (event before waiting for the exchange, event after) of the most recent steps: bounded, a long training run
+        # must not accumulate live hipEvents
+        self._exposed = collections.deque(maxlen=64)
         self._bytes = 0
+        self._msgs = 0
+        self._steps = 0
         model._grad_ready_hook = self._on_ready
 
+    def _resolve(self, flat: torch.Tensor) -> None:
+        if self.compress is None:
+            self.compress = "bf16" if flat.numel() * 4 > AUTO_BF16_BYTES else "none"
+
     def _exchange(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        self._resolve(flat)
         for a in range(lo, hi, self.bucket):
             b = min(hi, a + self.bucket)
             if self.compress == "bf16":
@@ -59,9 +77,11 @@ class GradSync:
                 self._half.append((half, flat[a:b]))
                 self.handles.append(dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
                 self._bytes += 2 * (b - a)
+                self._msgs += 1
             else:
                 self.handles.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
                 self._bytes += 4 * (b - a)
+                self._msgs += 1
 
     def _on_ready(self, flat: torch.Tensor, lo: int, hi: int, events=None) -> None:
         """Called by the trunk's backward when gflat[lo:hi] is final for this step: once `events` have passed
@@ -118,6 +138,7 @@ class GradSync:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(main)
             self._exposed.append((e0, e1))
+        self._steps += 1
         if self.optimizer is not None:
             self.optimizer.pending_grad_scale = inv      # consumed (and reset) by the next FusedAdam.step()
         else:
@@ -127,17 +148,22 @@ class GradSync:
     def reset_stats(self) -> None:
         self._exposed.clear()
         self._bytes = 0
+        self._msgs = 0
+        self._steps = 0
 
     def stats(self) -> dict:
         """Exposed exchange time per step: how long the main stream sat between the end of backward and the end of
         the last all-reduce (the part that did not overlap backward)."""
-        if not self._exposed:
-            return {"world": self.world, "steps": 0}
-        torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in self._exposed]
-        n = len(ms)
-        return {"world": self.world, "steps": n, "exposed_ms_per_step": round(sum(ms) / n, 3),
-                "bytes_per_step": self._bytes // n, "compress": self.compress}
+        if not self._steps:
+            return {"world": self.world, "steps": 0, "compress": self.compress or self.compress_arg}
+        n = self._steps
+        out = {"world": self.world, "steps": n, "bytes_per_step": self._bytes // n, "messages_per_step": self._msgs // n,
+               "bucket_bytes": self.bucket * 4, "compress": self.compress or self.compress_arg}
+        if self._exposed:
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self._exposed]
+            out["exposed_ms_per_step"] = round(sum(ms) / len(ms), 3)
+        return out
 
 
 def reduce_gradients_cpu(params, world: int, group=None) -> None:

@@ -249,11 +249,22 @@ class ParamStore:
         return self.shadow_flat.data_ptr() + self.shadow_flat.element_size() * (self._shadow_off[key] + elem_off)
 
     def mark_dirty(self) -> None:
-        """The master weights were changed through raw pointers (bpm_adam_step): the CT shadows are stale."""
+        """The master weights were changed through raw pointers (bpm_adam_step) or through a `p.data` alias (neither
+        bumps a version counter torch lets us see): the CT shadows are stale.  Writers of `p.data` MUST call this."""
         self._dirty = True
 
+    invalidate = mark_dirty
+
+    def broadcast(self, src: int = 0, group=None) -> None:
+        """Replicate rank `src`'s flat master on every rank (one message) and invalidate the shadows."""
+        import torch.distributed as dist
+        dist.broadcast(self.master, src, group=group)
+        self.mark_dirty()
+
     def _versions(self) -> int:
-        return sum(p._version for p in self.params.values())
+        # in-place ops on a parameter bump p._version; in-place ops on the flat master itself (dist.broadcast(master),
+        # master.mul_(..), EMA / averaging written on the master) bump master._version only
+        return self.master._version + sum(p._version for p in self.params.values())
 
     def refresh_shadows(self, force: bool = False) -> None:
         """Re-derive the CT weight shadows and folded biases from the fp32 masters -- only when the masters changed
@@ -770,6 +781,11 @@ class EncoderGroupPlan:
                     s_ln0.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R,
                                                 dy=b["dxn"], ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"),
                                                 dbeta=GP("layer_norms.0.bias"), **nxt))
+            # Ownership of parameter-gradient words (bpm_ln_bwd_ws adds its row sums with a plain read-modify-write):
+            # layer_norms.* / out_proj.bias / fc2.bias gradients are written by the MAIN stream's LayerNorm backward
+            # launches only, except layer_norms.{lnK} which unfold_grads (side stream) also adds to -- that launch is
+            # ordered behind lnq(i) / s_ln0(i) by the main_dirty event recorded before every SIDE step, and the next
+            # main-stream writer of the same words is the NEXT step's backward (behind the JOIN).  Keep it that way.
             # Side stream (SIDE): weight gradients and the key/value-side dgrad + LayerNorm backward -- nothing on
             # the backward critical path consumes them.  Temporaries are double-buffered by layer parity, so the
             # main chain only waits (WAIT) for the side work of two layers ago before overwriting them.

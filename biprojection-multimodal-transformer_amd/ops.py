@@ -241,7 +241,11 @@ def ln_bwd(probs, d, dtype=None, seed=0) -> None:
     dev = torch.device("cuda", torch.cuda.current_device())
     for sub, k in _chunks(arr, LnProblem, None):
         ws = _ln_workspace(k, d, dev)
-        _lib.check(_lib.lib().bpm_ln_bwd_ws(dt, sub, k, d, seed, ws.data_ptr(), ws.numel() * 4, _stream()), "bpm_ln_bwd_ws")
+        try:
+            _lib.check(_lib.lib().bpm_ln_bwd_ws(dt, sub, k, d, seed, ws.data_ptr(), ws.numel() * 4, _stream()), "bpm_ln_bwd_ws")
+        except RuntimeError:
+            _LN_WS.clear()          # an aborted launch may leave ticket words set: start from fresh zeroed workspaces
+            raise
 
 
 def cast_problem(a, lda, R, Cn, *, a_is_ct=False, b=None, ldb=0, dst_ct=None, ldd=0, ct_cols=0, dst_f32=None, ldf=0, colsum=None,

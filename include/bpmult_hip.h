@@ -225,7 +225,11 @@ int bpm_ln_bwd(int dtype, const bpm_ln_problem* probs, int n, int d, uint64_t se
 /* Same with a caller-provided workspace of at least bpm_ln_bwd_ws_bytes(n, d) bytes (16-byte aligned, private to the
  * stream, ZERO when first used -- the library leaves its ticket words zero again): dgamma / dbeta / cast_colsum are then
  * produced from per-block partial rows by the last block of each problem to finish (single owner per column, fixed
- * order: bitwise reproducible) instead of float atomics from every block into the same rows.  ws == NULL: as bpm_ln_bwd. */
+ * order: bitwise reproducible) instead of float atomics from every block into the same rows.  ws == NULL: as bpm_ln_bwd.
+ * The last block adds with a plain read-modify-write, so for the duration of the launch the stream must OWN those rows:
+ * no other stream may accumulate into the same dgamma / dbeta / cast_colsum words concurrently (problems of one launch
+ * that share a row are detected and fall back to atomics).  A launch that faults can leave ticket words non-zero:
+ * re-zero (or re-create) the workspace after any error reported for its stream. */
 size_t bpm_ln_bwd_ws_bytes(int n, int d);
 int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* probs, int n, int d, uint64_t seed, void* ws, size_t ws_bytes, void* stream);
 
@@ -349,6 +353,9 @@ enum { BPM_PROF_GEMM_NT = 0, BPM_PROF_GEMM_NN = 1, BPM_PROF_GEMM_TN = 2, BPM_PRO
        BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5, BPM_PROF_XBLOCK = 6 };
 int bpm_prof_enable(unsigned kind_mask);
 int bpm_prof_collect(int kind, double* total_ms, double* total_work, int* launches);
+/* The same, plus the launches' ALGORITHMIC HBM bytes (GEMM: both operands once, the output once, every side operand of
+ * the epilogue once -- residual, gate, the previous value for +=; attention: Q, K, V, O (+ dO, dQ, dK, dV) once). */
+int bpm_prof_collect2(int kind, double* total_ms, double* total_work, double* total_bytes, int* launches);
 
 #ifdef __cplusplus
 }

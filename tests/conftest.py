@@ -22,6 +22,10 @@ def pytest_collection_modifyitems(config, items):
     except Exception:  # pragma: no cover
         has_gpu = False
     if has_gpu:
+        # the one-GPU-per-rank RCCL test first, before this process has touched a GPU (its ranks are spawned processes)
+        first = [it for it in items if "rccl" in it.name]
+        if first:
+            items[:] = first + [it for it in items if it not in first]
         return
     skip = pytest.mark.skip(reason="no GPU in this container (gpu tests run on the MI355X box)")
     for it in items:

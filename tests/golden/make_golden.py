@@ -323,6 +323,13 @@ def f9_cfg1():
     _three_modal("f9_cfg1", "f9.", 300, 12, 8, 2, 20, 500, 400, 768, small_only=True)
 
 
+def f11_h768():
+    """The bench's headline workload (BASELINE.json metric: hidden 768, 3-modal unaligned): `mmtrvat` at d=768, 12 heads
+    (head_dim 64), 8 layers, orig_d 768/35/74 (proj_l skipped: mmtr.py:748), L/V/A = 20/500/400 -> 512, B=1.  680 M
+    parameters: logits, gates, loss, every parameter's gradient norm, the small full gradients, the input gradients."""
+    _three_modal("f11_h768", "f11.", 768, 12, 8, 1, 20, 500, 400, 768, small_only=True)
+
+
 def f8_mmtrvapt():
     pfx = "f8."
     d, H, Ly, B = 24, 4, 2, 2
@@ -398,7 +405,7 @@ def f10_cfg3():
 
 
 ALL = dict(f1=f1_posemb, f2=f2_mask, f3=f3_mha, f4=f4_layer, f5=f5_encoder, f6=f6_gmu,
-           f7=f7_mmtrvat, f8=f8_mmtrvapt, f9=f9_cfg1, f10=f10_cfg3)
+           f7=f7_mmtrvat, f8=f8_mmtrvapt, f9=f9_cfg1, f10=f10_cfg3, f11=f11_h768)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

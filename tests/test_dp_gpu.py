@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, backend="gloo"):
+def _worker(rank, world, port, out, backend="gloo", compress="none"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -51,7 +51,7 @@ def _worker(rank, world, port, out, backend="gloo"):
     B = 4
     xs = [torch.randn(B, 30, 32, generator=g).cuda(), torch.randn(B, 64, 35, generator=g).cuda(), torch.randn(B, 50, 74, generator=g).cuda()]
     tgt = (torch.randn(B, 6, generator=g) > 0).float().cuda()
-    sync = GradSync(model, bucket_bytes=1 << 16)          # small buckets: several all-reduces per section
+    sync = GradSync(model, bucket_bytes=1 << 16, compress=compress)   # small buckets: several all-reduces per section
 
     def run(sl):
         for p in model.parameters():
@@ -105,14 +105,28 @@ def test_gradsync_two_ranks_equals_global_batch_gradient():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the one-GPU box runs the gloo variant above")
-def test_gradsync_rccl_two_gpus_with_accumulation():
+@pytest.mark.parametrize("compress", ["none", "bf16"])
+def test_gradsync_rccl_two_gpus_with_accumulation(compress):
     """backend "nccl" (= RCCL), one GPU per rank: per-layer slice all-reduces on the communication stream gated by main- and
-    side-stream events, prezero on the side stream beside in-flight exchanges, one accumulation micro-step."""
+    side-stream events, prezero on the side stream beside in-flight exchanges, one accumulation micro-step; fp32 slices
+    and bf16 copies (conftest.py runs these first wherever two GPUs are visible)."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out, "nccl"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, "nccl", compress), nprocs=world, join=True)
     assert len(out) == world
     for r, e in out.items():
-        assert e < 2e-4, (r, e)
+        assert e < (2e-4 if compress == "none" else 2e-2), (r, e)
+
+
+def test_gradsync_two_ranks_bf16_slices():
+    """The same exchange with bf16 copies of the slices (the default above 1 GiB of gradients), two ranks on this GPU."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out, "gloo", "bf16"), nprocs=world, join=True)
+    assert len(out) == world
+    for r, e in out.items():
+        assert e < 2e-2, (r, e)

@@ -74,10 +74,14 @@ def _worker(rank, world, port, out):
     total = sum(sizes.values())
     gen = lambda r, step: torch.randn(total + 8, generator=torch.Generator().manual_seed(100 * r + step))
     res = {}
-    for mode in ("plain", "optimizer", "bf16"):
+    import bpmult_amd.distributed as D
+    for mode in ("plain", "optimizer", "bf16", "auto_small", "auto_big"):
         model = _Model(sizes)
         opt = SimpleNamespace(pending_grad_scale=None) if mode == "optimizer" else None
-        sync = GradSync(model, bucket_bytes=4 * 256, optimizer=opt, compress="bf16" if mode == "bf16" else "none")
+        # default compress="auto": fp32 slices below AUTO_BF16_BYTES of gradients, bf16 copies above
+        D.AUTO_BF16_BYTES = 4 * total - 4 if mode == "auto_big" else 1 << 30
+        kw = {} if mode.startswith("auto") else {"compress": "bf16" if mode == "bf16" else "none"}
+        sync = GradSync(model, bucket_bytes=4 * 256, optimizer=opt, **kw)
         # two accumulation micro-steps: only the second one exchanges
         for step, active in ((0, False), (1, True)):
             sync.active = active
@@ -92,6 +96,10 @@ def _worker(rank, world, port, out):
         err = float((got - want * scale).abs().max() / want.abs().max())
         if mode == "optimizer":
             assert opt.pending_grad_scale == 1.0 / world
+        if mode.startswith("auto"):
+            assert sync.compress == ("bf16" if mode == "auto_big" else "none"), (mode, sync.compress)
+            st = sync.stats()
+            assert st["messages_per_step"] >= 5 and st["bytes_per_step"] > 0, st
         res[mode] = err
     out[rank] = res
     dist.destroy_process_group()
@@ -104,5 +112,5 @@ def test_gradsync_sections_accumulation_tail_and_compression():
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert len(out) == world
     for r, e in out.items():
-        assert e["plain"] < 1e-6 and e["optimizer"] < 1e-6, (r, e)
-        assert e["bf16"] < 2e-2, (r, e)          # one bf16 rounding of each summand and of the sum
+        assert e["plain"] < 1e-6 and e["optimizer"] < 1e-6 and e["auto_small"] < 1e-6, (r, e)
+        assert e["bf16"] < 2e-2 and e["auto_big"] < 2e-2, (r, e)     # one bf16 rounding of each summand and of the sum

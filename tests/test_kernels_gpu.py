@@ -514,6 +514,32 @@ def test_gemm_hardware_bounded_loader(dtype, variant):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("variant,M,N,K", [(GEMM_TN, 200, 96, 333), (GEMM_NN, 333, 96, 200), (GEMM_TN, 768, 768, 1000), (GEMM_NN, 1000, 768, 768)])
+def test_gemm_operand_column_view_at_the_end_of_its_allocation(dtype, variant, M, N, K):
+    """The hardware-bounded loaders size their buffer descriptors from each operand VIEW: (rows - 1) leading dimensions
+    plus the last row's width.  Operand A here is the LAST column block of a [rows, 3 ld] buffer (the dQ | dK | dV layout
+    of engine.py) whose allocation ends exactly with that view, followed by poison: everything the kernels may touch past
+    the view's last row must come back as zeros from the range check, never as the neighbour's bytes."""
+    from bpmult_amd.ops import F_KPAD
+    ct = ops.ct_torch(dtype)
+    rows, cols = (K, M) if variant == GEMM_TN else (M, K)          # A is [K, M] (TN) or [M, K] (NN)
+    ld = pad32(cols)
+    A32 = rnd(rows, cols, seed=3)
+    flat = torch.full((rows * 3 * ld + 4096,), float("nan"), dtype=ct)    # the view ends where the poison starts
+    wide = flat[:rows * 3 * ld].view(rows, 3 * ld)
+    wide.zero_()
+    wide[:, 2 * ld:2 * ld + cols] = A32.to(ct)
+    flat = flat.to(DEV)
+    A = flat[:rows * 3 * ld].view(rows, 3 * ld)[:, 2 * ld:]
+    Ar = A32.to(ct).float()
+    Bm, Br = to_ct(rnd(K, N, seed=4, scale=K ** -0.5), dtype)
+    ref = (Ar.double().T if variant == GEMM_TN else Ar.double()) @ Br.double()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_grouped(dtype, variant, [ops.gemm_problem(A, Bm, out, M, N, K, 3 * ld, Bm.shape[1], N, flags=F_KPAD)])
+    close(out, ref, tol(dtype) if dtype == BPM_F32 else 2e-3, f"column-view operand, variant {variant}")
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_kv_layernorm_folding(dtype):
     """pack_weights(colscale) + fold_bias + unfold_grads reproduce y = LN(x; gamma, beta) W^T + b and its gradients
     from the un-affined normalised source (the engine's key / value path)."""

@@ -246,3 +246,22 @@ def test_f10_cfg3_shape_logits():
         logits, z = O.bpmult4_forward(sd, m, xl, img, af, post)
     close(logits, g["logits"], 1e-4, "logits")
     close(z, g["z"], 1e-4, "z")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "f11_h768.npz")), reason="f11 fixture not generated")
+def test_f11_headline_shape_logits():
+    """The bench's headline workload (BASELINE.json metric: hidden 768, 3-modal unaligned; mmtr.py:587-866): `mmtrvat`
+    at d=768, 12 heads (head_dim 64), 8 layers, L/V/A = 20/500/400 -> 512, B=1: forward only here (680 M parameters; the
+    backward is compared on the GPU against the stored gradient norms, small gradients and input gradients)."""
+    g = load("f11_h768")
+    pfx = "f11."
+    m = O.ModelCfg(768, 12, 8, 6, orig_d_l=768)
+    shapes = O.model_param_shapes(m, False)
+    ref = dict(zip(g["param_names"].tolist(), g["param_shapes"].tolist()))
+    assert {k: ",".join(map(str, v)) for k, v in shapes.items()} == ref
+    sd = {k: T(det_param(pfx + k, s)) for k, s in shapes.items()}
+    xl, img, aud = (T(det(pfx + n, s)) for n, s in (("xl", (1, 20, 768)), ("img", (1, 500, 35)), ("aud", (1, 400, 74))))
+    with torch.no_grad():
+        logits, z = O.bpmult3_forward(sd, m, xl, img, aud)
+    close(logits, g["logits"], 1e-4, "logits")
+    close(z, g["z"], 1e-4, "z")
