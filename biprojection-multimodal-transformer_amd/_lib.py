@@ -17,10 +17,10 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BPMULT_LIB", os.path.join(_HERE, "libbpmult_hip.so"))   # override: kernel-variant experiments
-SOURCES = ("gemm.hip", "attention.hip", "xblock.hip", "rowops.hip", "tail.hip", "frontend.hip", "prof.hip")
+SOURCES = ("gemm.hip", "attention.hip", "rowops.hip", "tail.hip", "frontend.hip", "prof.hip")
 HEADERS = ("bpm_common.h", "bpm_prof.h", "gemm_dma.h")
 ARCH = "gfx950"
-PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5, "xblock": 6}
+PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5}
 
 BPM_F32, BPM_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
@@ -28,6 +28,7 @@ OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
 F_ACCUM, F_RELU, F_ATOMIC, F_KPAD, F_BACKGROUND = 1, 2, 4, 8, 16     # F_KPAD = BPM_GEMM_KPAD_ZERO
 LN_OUT_F32 = 2
 MAX_GROUP = 18
+SEED_INDIRECT = 1 << 63          # seed = SEED_INDIRECT | device address of a uint64 (include/bpmult_hip.h)
 GEMM_MAX_GROUP = 24
 
 
@@ -145,15 +146,6 @@ class GmuProblem(C.Structure):
                 ("ldg", C.c_int), ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("R", C.c_int)]
 
 
-class XBlockProblem(C.Structure):
-    _fields_ = [("xq", C.c_void_p), ("xk", C.c_void_p), ("xv", C.c_void_p),
-                ("Wq", C.c_void_p), ("bq", C.c_void_p), ("Wk", C.c_void_p), ("bk", C.c_void_p), ("Wv", C.c_void_p), ("bv", C.c_void_p),
-                ("Wo", C.c_void_p), ("bo", C.c_void_p), ("resid", C.c_void_p), ("out", C.c_void_p),
-                ("qh", C.c_void_p), ("kh", C.c_void_p), ("vh", C.c_void_p), ("ao", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p),
-                ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("S", C.c_int), ("d", C.c_int), ("ld", C.c_int), ("mask_off", C.c_int),
-                ("scale", C.c_float), ("attn_drop", C.c_float), ("attn_site", C.c_uint32), ("res_drop", C.c_float), ("res_site", C.c_uint32)]
-
-
 class TailDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("d", C.c_int), ("n", C.c_int), ("C", C.c_int), ("N", C.c_int * 3),
                 ("top", C.c_void_p * 3), ("mid", C.c_void_p * 3), ("extra", C.c_void_p),
@@ -200,7 +192,6 @@ SIGNATURES = {
     "bpm_col2im1d": [_P, _P, _I, _I, _I, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _I, _P],
     "bpm_adaptive_pool1d_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "bpm_adaptive_pool1d_bwd": [_P, _P, _I, _I, _I, _I, _P],
-    "bpm_xblock_fwd": [_I, C.POINTER(XBlockProblem), _I, _U64, _P],
     "bpm_tail_fwd": [C.POINTER(TailDesc), _U64, _P],
     "bpm_tail_bwd": [C.POINTER(TailDesc), C.POINTER(TailGrads), _P],
     "bpm_adam_step": [_P, _P, _P, _P, C.c_size_t, _F, _F, _F, _F, _F, _I, _F, _I, _P],
@@ -235,6 +226,21 @@ def lib() -> C.CDLL:
             raise HipLibraryError("libbpmult_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+_prof_mask = 0
+
+
+def prof_enable(mask: int) -> None:
+    """bpm_prof_enable; remembered host-side: while the launch profiler records, steps run eagerly (a graph replay
+    launches nothing from the host, so there would be nothing to bracket with events)."""
+    global _prof_mask
+    lib().bpm_prof_enable(mask)
+    _prof_mask = mask
+
+
+def prof_enabled() -> bool:
+    return _prof_mask != 0
 
 
 _DEBUG_SYNC = bool(int(os.environ.get("BPMULT_DEBUG_SYNC", "0")))

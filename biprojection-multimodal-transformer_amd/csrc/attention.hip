@@ -104,6 +104,7 @@ struct AProb {
     int pair;           // workgroups take two blocks (b, nblk - 1 - b) instead of one
 };
 struct AGroup {
+    const uint64_t* seedp;     // dropout seed read at execution time (BPM_SEED_INDIRECT), or nullptr
     int nprob;
     AProb p[BPM_MAX_GROUP];
 };
@@ -226,7 +227,7 @@ BPM_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_ex
 // forward
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-BPM_DEV void attn_fwd_block(const AProb& P, char* smem, const int bh, const int qb) {
+BPM_DEV void attn_fwd_block(const AProb& P, const DropCfg& drop, char* smem, const int bh, const int qb) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     char* kimg = smem;
@@ -257,7 +258,7 @@ BPM_DEV void attn_fwd_block(const AProb& P, char* smem, const int bh, const int 
     const int ntile = (jend + KT - 1) / KT;
     const int lim = min(P.S, P.qpos0 + q * P.qstride + P.mask_off);          // this lane sees keys j < lim
     const int lim_min = min(P.S, P.qpos0 + q0 * P.qstride + P.mask_off);     // every lane of the wave sees keys j < lim_min
-    const bool dropping = P.drop.thresh != 0;
+    const bool dropping = drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
     const bool pair_ok = (P.S & 3) == 0;               // row starts are multiples of 4: keys (4m .. 4m+3) are one hash quad
 
@@ -316,14 +317,14 @@ BPM_DEV void attn_fwd_block(const AProb& P, char* smem, const int bh, const int 
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     float d0, d1, d2, d3;
-                    bpm_drop_mult4(P.drop, drow + (uint32_t)(jb + 16 * n), d0, d1, d2, d3);
+                    bpm_drop_mult4(drop, drow + (uint32_t)(jb + 16 * n), d0, d1, d2, d3);
                     st[n] *= f32x4{d0, d1, d2, d3};
                 }
             } else {
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) st[n][r] *= bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+                    for (int r = 0; r < 4; ++r) st[n][r] *= bpm_drop_mult(drop, drow + (uint32_t)(jb + 16 * n + r));
             }
         }
         l_run = l_run * alpha + psum;
@@ -365,12 +366,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
     if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const int nb2 = P.pair ? (P.nblk + 1) >> 1 : P.nblk;
     const int bh = bid / nb2, first = P.pair ? bid % nb2 : P.nblk - 1 - bid % nb2, second = P.pair ? P.nblk - 1 - first : first;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (pass && second == first) break;
-        attn_fwd_block<CT, DHP>(P, smem, bh, pass ? second : first);
+        attn_fwd_block<CT, DHP>(P, drop, smem, bh, pass ? second : first);
     }
 }
 
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 // backward, dQ (and delta = rowsum(dO * O))
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-BPM_DEV void attn_bwd_dq_block(const AProb& P, char* smem, const int bh, const int qb) {
+BPM_DEV void attn_bwd_dq_block(const AProb& P, const DropCfg& drop, char* smem, const int bh, const int qb) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     char* kimg = smem;
@@ -433,7 +435,7 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, char* smem, const int bh, const i
     const int ntile = (jend + KT - 1) / KT;
     const int lim = min(P.S, P.qpos0 + q * P.qstride + P.mask_off);
     const int lim_min = min(P.S, P.qpos0 + q0 * P.qstride + P.mask_off);
-    const bool dropping = P.drop.thresh != 0;
+    const bool dropping = drop.thresh != 0;
     const uint32_t drow = ((uint32_t)bh * (uint32_t)P.T + (uint32_t)q) * (uint32_t)P.S;
     const bool pair_ok = (P.S & 3) == 0;               // row starts are multiples of 4: keys (4m .. 4m+3) are one hash quad
 
@@ -466,10 +468,10 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, char* smem, const int bh, const i
                 float dm[4] = {1.f, 1.f, 1.f, 1.f};
                 if (dropping) {
                     if (pair_ok) {
-                        bpm_drop_mult4(P.drop, drow + (uint32_t)(jb + 16 * n), dm[0], dm[1], dm[2], dm[3]);
+                        bpm_drop_mult4(drop, drow + (uint32_t)(jb + 16 * n), dm[0], dm[1], dm[2], dm[3]);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dm[r] = bpm_drop_mult(P.drop, drow + (uint32_t)(jb + 16 * n + r));
+                        for (int r = 0; r < 4; ++r) dm[r] = bpm_drop_mult(drop, drow + (uint32_t)(jb + 16 * n + r));
                     }
                 }
                 f32x4 e4 = s_ * LOG2E + lse2;
@@ -513,12 +515,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
     if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const int nb2 = P.pair ? (P.nblk + 1) >> 1 : P.nblk;
     const int bh = bid / nb2, first = P.pair ? bid % nb2 : P.nblk - 1 - bid % nb2, second = P.pair ? P.nblk - 1 - first : first;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (pass && second == first) break;
-        attn_bwd_dq_block<CT, DHP>(P, smem, bh, pass ? second : first);
+        attn_bwd_dq_block<CT, DHP>(P, drop, smem, bh, pass ? second : first);
     }
 }
 
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 // backward, dK and dV
 // ---------------------------------------------------------------------------
 template <typename CT, int DHP>
-BPM_DEV void attn_bwd_dkv_block(const AProb& P, char* smem, const int bh, const int kb) {
+BPM_DEV void attn_bwd_dkv_block(const AProb& P, const DropCfg& drop, char* smem, const int bh, const int kb) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
     char* qimg = smem;
@@ -564,7 +567,7 @@ BPM_DEV void attn_bwd_dkv_block(const AProb& P, char* smem, const int bh, const 
     const int i_first = first_row(kb * 64 - P.mask_off + 1);                                   // first query row that sees any key of the block
     const int qt_lo = i_first / QT;
     const int qt_hi = (P.T + QT - 1) / QT;
-    const bool dropping = P.drop.thresh != 0;
+    const bool dropping = drop.thresh != 0;
 
     RowStage<CT, DHP, QT> qst, dost;
     float n_lse = 0.f, n_del = 0.f;                    // threads < QT: next tile's -lse*log2(e) and delta
@@ -618,7 +621,7 @@ BPM_DEV void attn_bwd_dkv_block(const AProb& P, char* smem, const int bh, const 
                 if (dropping) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        dm4[r] = bpm_drop_mult(P.drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
+                        dm4[r] = bpm_drop_mult(drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
                 }
                 pd[uu] = p4 * dm4;
                 ds[uu] = p4 * (dp * dm4 - d4);
@@ -659,12 +662,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
     if (BPM_BASE_PRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const AProb& P = pick(grp, bid);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const int nb2 = P.pair ? (P.nblk + 1) >> 1 : P.nblk;
     const int bh = bid / nb2, first = P.pair ? bid % nb2 : bid % nb2, second = P.pair ? P.nblk - 1 - first : first;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (pass && second == first) break;
-        attn_bwd_dkv_block<CT, DHP>(P, smem, bh, pass ? second : first);
+        attn_bwd_dkv_block<CT, DHP>(P, drop, smem, bh, pass ? second : first);
     }
 }
 
@@ -674,6 +678,7 @@ int g_attn_pair = 7;
 int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S, uint64_t seed, int* total, int kernel) {
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
     g.nprob = nprob;
+    g.seedp = bpm_seed_ptr(seed);
     int blk = 0;
     for (int i = 0; i < nprob; ++i) {
         const bpm_attn_problem& q = probs[i];

@@ -46,22 +46,35 @@ BPM_DEV void bpm_hash64(uint32_t q, uint32_t key, uint32_t& w0, uint32_t& w1) {
     w1 = a * 0x27D4EB2Fu;
     w1 ^= w1 >> 15;
 }
-// host side: fold (seed, site) into the 32-bit hash key
-static inline uint32_t bpm_host_drop_key(uint64_t seed, uint32_t site) {
+// fold (seed, site) into the 32-bit hash key.  Host side for a seed passed by value; device side when the seed is read
+// from memory at execution time (BPM_SEED_INDIRECT: a captured hipGraph replays with a fresh seed per step)
+__host__ __device__ static inline uint32_t bpm_host_drop_key(uint64_t seed, uint32_t site) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1u);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
     return (uint32_t)(z ^ (z >> 32));
 }
+// `seed` argument of every bpm_* entry: a 63-bit value, or BPM_SEED_INDIRECT | address of a device uint64 the kernels
+// read when they RUN.  Indirect: DropCfg.key carries the raw site and bpm_resolve_drop() finishes the key on the device
+// with the same function, so both forms draw identical masks for the same seed value.
+#define BPM_SEED_INDIRECT_BIT (1ull << 63)   // == BPM_SEED_INDIRECT of include/bpmult_hip.h
+static inline const uint64_t* bpm_seed_ptr(uint64_t seed) {
+    return (seed & BPM_SEED_INDIRECT_BIT) ? (const uint64_t*)(uintptr_t)(seed & ~BPM_SEED_INDIRECT_BIT) : nullptr;
+}
 static inline DropCfg bpm_make_drop(float p, uint64_t seed, uint32_t site) {
     DropCfg d;
     d.thresh = 0; d.key = 0; d.inv_keep = 1.f;
     if (p > 0.f) {
         d.thresh = (uint32_t)(p * 65536.0 + 0.5);
-        d.key = bpm_host_drop_key(seed, site);
+        d.key = (seed & BPM_SEED_INDIRECT_BIT) ? site : bpm_host_drop_key(seed, site);
         d.inv_keep = 1.f / (1.f - p);
     }
+    return d;
+}
+BPM_DEV DropCfg bpm_resolve_drop(const DropCfg& c, const uint64_t* seedp) {
+    DropCfg d = c;
+    if (seedp != nullptr && c.thresh != 0) d.key = bpm_host_drop_key(*seedp, c.key);
     return d;
 }
 // multiplier applied to a kept element; 0 for a dropped one.  Element idx takes 16 bits of the hash of its quad idx >> 2:

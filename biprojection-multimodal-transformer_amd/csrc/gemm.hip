@@ -104,6 +104,7 @@ struct Prob {                              // 168 bytes: 24 of them (+ the heade
 static_assert(sizeof(Prob) == 168, "Prob layout");
 
 struct Group {
+    const uint64_t* seedp;     // dropout seed read at execution time (BPM_SEED_INDIRECT), or nullptr
     int nprob;
     int total_tiles;
     Prob p[BPM_GEMM_MAX_GROUP];
@@ -135,7 +136,7 @@ BPM_DEV void store_ct4(char* C, size_t off_elems, const float (&v)[4], int nvali
 }
 
 template <typename CT>
-BPM_DEV void epilogue_tile(const Prob& P, bool lead, int m, int nb, const f32x4& acc, float (&csum)[4]) {
+BPM_DEV void epilogue_tile(const Prob& P, const DropCfg& drop, bool lead, int m, int nb, const f32x4& acc, float (&csum)[4]) {
     if (m >= P.M) return;
     const bool atomic = (P.flags & BPM_GEMM_ATOMIC) != 0;
     const bool accum = (P.flags & BPM_GEMM_ACCUM) != 0;
@@ -172,13 +173,13 @@ BPM_DEV void epilogue_tile(const Prob& P, bool lead, int m, int nb, const f32x4&
     }
     const float bm = (lead && P.bias_m) ? P.bias_m[m] : 0.f;
     float dm[4] = {1.f, 1.f, 1.f, 1.f};
-    if (P.drop.thresh != 0) {
+    if (drop.thresh != 0) {
         const uint32_t i0 = (uint32_t)m * (uint32_t)P.N + (uint32_t)nb;
         if ((i0 & 3u) == 0) {                       // nb .. nb+3 is one hash quad
-            bpm_drop_mult4(P.drop, i0, dm[0], dm[1], dm[2], dm[3]);
+            bpm_drop_mult4(drop, i0, dm[0], dm[1], dm[2], dm[3]);
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dm[q] = bpm_drop_mult(P.drop, i0 + q);
+            for (int q = 0; q < 4; ++q) dm[q] = bpm_drop_mult(drop, i0 + q);
         }
     }
 #pragma unroll
@@ -312,7 +313,7 @@ BPM_DEV void epi_fast_load(const Prob& P, int mrow, int nb, EpiSide<CT, NB>& s) 
 }
 
 template <typename CT, int NB>
-BPM_DEV void epi_fast_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NB], const EpiSide<CT, NB>& s, f32x4& csum) {
+BPM_DEV void epi_fast_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NB], const EpiSide<CT, NB>& s, f32x4& csum) {
     const bool colok = nb < P.N;                        // N % 4 == 0: a lane's 4 columns are all in or all out
     const bool f32out = P.out_kind == BPM_OUT_F32;
 #pragma unroll
@@ -331,9 +332,9 @@ BPM_DEV void epi_fast_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[
 #pragma unroll
                 for (int q = 0; q < 4; ++q) x[q] = (float)s.gt[b][q] > 0.f ? x[q] * P.gate_scale : 0.f;
             }
-            if (P.drop.thresh != 0) {                   // m*N + nb is a multiple of 4: one hash quad
+            if (drop.thresh != 0) {                     // m*N + nb is a multiple of 4: one hash quad
                 float d0, d1, d2, d3;
-                bpm_drop_mult4(P.drop, e.didx + (uint32_t)nb, d0, d1, d2, d3);
+                bpm_drop_mult4(drop, e.didx + (uint32_t)nb, d0, d1, d2, d3);
                 x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
             }
             csum += x;
@@ -366,23 +367,23 @@ BPM_DEV void epi_fast_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[
 }
 
 template <typename CT, int NB>
-BPM_DEV void epilogue_fast(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NB], f32x4& csum) {
+BPM_DEV void epilogue_fast(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NB], f32x4& csum) {
     EpiSide<CT, NB> s;
     epi_fast_load<CT, NB>(P, mrow, nb, s);
-    epi_fast_apply<CT, NB>(P, mrow, nb, acc, s, csum);
+    epi_fast_apply<CT, NB>(P, drop, mrow, nb, acc, s, csum);
 }
 
 // one wave's column block: rows (m0 + 16*b + r), b < NB, columns nb..nb+3
 template <typename CT, int NB>
-BPM_DEV void epilogue_cols(const Prob& P, bool fast, bool lead, int m0, int r, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB]) {
+BPM_DEV void epilogue_cols(const Prob& P, const DropCfg& drop, bool fast, bool lead, int m0, int r, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB]) {
     if (fast) {
         f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-        epilogue_fast<CT, NB>(P, m0 + r, nb, acc, cs);
+        epilogue_fast<CT, NB>(P, drop, m0 + r, nb, acc, cs);
         if (P.colsum) { float c4[4] = {cs[0], cs[1], cs[2], cs[3]}; flush_colsum(P, c4, nb, r); }
     } else {
         float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < NB; ++b) epilogue_tile<CT>(P, lead, m0 + 16 * b + r, nb, acc[b], csum);
+        for (int b = 0; b < NB; ++b) epilogue_tile<CT>(P, drop, lead, m0 + 16 * b + r, nb, acc[b], csum);
         if (P.colsum) flush_colsum(P, csum, nb, r);
     }
 }
@@ -708,6 +709,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
     }
     if (kt_lo >= kt_hi && !lead) return;
     const bool fast = epi_fast_ok(P);                   // wave-uniform
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const int mw = m0 + wm * (BMT / WM);
     EpiRow rows[TMT];
 #pragma unroll
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
     auto epi = [&](auto A) {           // colsum shuffles: uniform per workgroup, every lane takes part
         constexpr int a = decltype(A)::value;
         if constexpr (a < TN) {
-            epilogue_cols<CT, TMT>(P, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows);
+            epilogue_cols<CT, TMT>(P, drop, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows);
             BPM_TRACE(13 + a);
         }
     };
@@ -906,6 +908,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         if (t128 < 2 * 256) bm_tile = 64;
     }
     Group g;
+    g.seedp = bpm_seed_ptr(seed);
     g.nprob = nprob;
     int tile = 0;
     for (int i = 0; i < nprob; ++i) {

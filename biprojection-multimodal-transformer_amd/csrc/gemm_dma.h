@@ -31,6 +31,9 @@
 // overhang of a k-strided operand only reaches output columns the epilogue masks.  k-contiguous operands must keep
 // whole 128-byte stages inside their zero-padded rows (checked by the dispatcher).
 
+#ifndef BPM_EPI_AHEAD
+#define BPM_EPI_AHEAD 1       // 16-row epilogue steps whose side operands are in flight ahead of their use (8-wave configurations)
+#endif
 #ifndef BPM_DMA_ABLATE
 #define BPM_DMA_ABLATE 0      // lab builds only (tools/gemm_lab.py): 1 no MFMA, 2 no DMA in the loop, 4 no epilogue
 #endif
@@ -101,7 +104,7 @@ BPM_DEV void wide_load(const Prob& P, int mrow, int nb, WideSide<NI>& s) {
 
 // rows mrow + 4 * i (i < NI), columns nb .. nb + 3
 template <int NI>
-BPM_DEV void wide_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NI], const f32x4 bias, const WideSide<NI>& s, f32x4& csum) {
+BPM_DEV void wide_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NI], const f32x4 bias, const WideSide<NI>& s, f32x4& csum) {
     const bool colok = nb < P.N;
     const bool f32out = P.out_kind == BPM_OUT_F32;
 #pragma unroll
@@ -120,9 +123,9 @@ BPM_DEV void wide_apply(const Prob& P, int mrow, int nb, const f32x4 (&acc)[NI],
 #pragma unroll
                 for (int q = 0; q < 4; ++q) x[q] = (float)s.gt[i][q] > 0.f ? x[q] * P.gate_scale : 0.f;
             }
-            if (P.drop.thresh != 0) {
+            if (drop.thresh != 0) {
                 float d0, d1, d2, d3;
-                bpm_drop_mult4(P.drop, e.didx + (uint32_t)nb, d0, d1, d2, d3);
+                bpm_drop_mult4(drop, e.didx + (uint32_t)nb, d0, d1, d2, d3);
                 x[0] *= d0; x[1] *= d1; x[2] *= d2; x[3] *= d3;
             }
             csum += x;
@@ -366,11 +369,14 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
     if (P.bias_n) bias = *(const f32x4*)(P.bias_n + (nbw < P.N ? nbw : 0));
-    // side operands of 16-row step h live in sd[h & 1], requested during step h - 1 -- where the register budget allows:
-    // the 16-wave configuration (128 registers) spills with two sets and requests them right before their use
-    constexpr bool AHEAD = NW < 16;
-    WideSide<4> sd[2];
-    if constexpr (AHEAD) wide_load<4>(P, mw + lr, nbw, sd[0]);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
+    // side operands of 16-row step h live in sd[h % (AH + 1)], requested AH steps before their use -- where the register
+    // budget allows: the 16-wave configuration (128 registers) spills with two sets and requests them right before their use
+    constexpr int AH = NW < 16 ? BPM_EPI_AHEAD : 0;
+    WideSide<4> sd[AH + 1];
+#pragma unroll
+    for (int h0 = 0; h0 < AH; ++h0)
+        if (h0 < TMW) wide_load<4>(P, mw + 16 * h0 + lr, nbw, sd[h0]);
     auto pass = [&](auto PB) {             // rows 32 PB .. 32 PB + 31 of the wave tile
         constexpr int pb = decltype(PB)::value;
         if constexpr (pb < TMW / 2) {
@@ -384,15 +390,14 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {           // 16 rows at a time: 4 row steps per lane in flight
                 const int h = 2 * pb + hf;
-                if constexpr (AHEAD) { if (h + 1 < TMW) wide_load<4>(P, mw + 16 * (h + 1) + lr, nbw, sd[(hf + 1) & 1]); }
-                else wide_load<4>(P, mw + 16 * h + lr, nbw, sd[hf & 1]);
+                if (h + AH < TMW || AH == 0) wide_load<4>(P, mw + 16 * (h + AH) + lr, nbw, sd[(h + AH) % (AH + 1)]);
                 f32x4 v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 16 * hf + 4 * i + lr;
                     v[i] = *(const f32x4*)(blk + row * 256 + ((lc ^ (row & 15)) << 4));
                 }
-                wide_apply<4>(P, mw + 16 * h + lr, nbw, v, bias, sd[hf & 1], cs);
+                wide_apply<4>(P, drop, mw + 16 * h + lr, nbw, v, bias, sd[h % (AH + 1)], cs);
             }
         }
     };

@@ -39,6 +39,7 @@ inline unsigned blocks_for(size_t n, int per_block, unsigned cap) {
 }
 
 template <typename P> struct Grp {
+    const uint64_t* seedp;              // dropout seed read at execution time (BPM_SEED_INDIRECT), or nullptr
     int n;
     unsigned blk0[BPM_MAX_GROUP + 1];   // prefix of block counts
     P p[BPM_MAX_GROUP];
@@ -67,6 +68,7 @@ template <typename CT>
 __global__ void pack_rows_fwd_kernel(const Grp<PackP> grp) {
     unsigned bid = blockIdx.x, nblk;
     const PackP& P = pick(grp, bid, nblk);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const size_t total = (size_t)P.T * P.B * P.ld;
     for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
         const int c = (int)(i % P.ld);
@@ -75,7 +77,7 @@ __global__ void pack_rows_fwd_kernel(const Grp<PackP> grp) {
         float v = 0.f;
         if (c < P.C) {
             const size_t si = ((size_t)b * P.T + t) * P.C + c;
-            v = P.src[si] * bpm_drop_mult(P.drop, (uint32_t)si);
+            v = P.src[si] * bpm_drop_mult(drop, (uint32_t)si);
         }
         put<CT>(P.dst, i, v);
     }
@@ -85,12 +87,13 @@ __global__ void pack_rows_fwd_kernel(const Grp<PackP> grp) {
 __global__ void pack_rows_bwd_kernel(const Grp<PackP> grp) {
     unsigned bid = blockIdx.x, nblk;
     const PackP& P = pick(grp, bid, nblk);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const size_t total = (size_t)P.T * P.B * P.C;
     for (size_t si = (size_t)bid * NT + threadIdx.x; si < total; si += (size_t)nblk * NT) {
         const int c = (int)(si % P.C);
         const size_t bt = si / P.C;
         const int t = (int)(bt % P.T), b = (int)(bt / P.T);
-        P.dsrc[si] = P.g[((size_t)t * P.B + b) * P.ldg + c] * bpm_drop_mult(P.drop, (uint32_t)si);
+        P.dsrc[si] = P.g[((size_t)t * P.B + b) * P.ldg + c] * bpm_drop_mult(drop, (uint32_t)si);
     }
 }
 
@@ -198,6 +201,7 @@ BPM_DEV bool emb_wide(const EmbP& P, const float* table, int d, size_t total) {
 __global__ void embed_pos_fwd_kernel(const Grp<EmbP> grp, const float* __restrict__ table, int d, float scale) {
     unsigned bid = blockIdx.x, nblk;
     const EmbP& P = pick(grp, bid, nblk);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const size_t total = (size_t)P.T * P.B * d;
     if (emb_wide(P, table, d, total)) {
         const uint32_t total4 = (uint32_t)(total >> 2), ud = (uint32_t)d;
@@ -206,9 +210,9 @@ __global__ void embed_pos_fwd_kernel(const Grp<EmbP> grp, const float* __restric
             const int t = (int)(row / (uint32_t)P.B);
             const int pos = (P.x[(size_t)row * ud] != 0.f) ? P.pos0 + t * P.pstride + 1 : 0;
             f32x4 v = scale * *(const f32x4*)(P.x + i) + *(const f32x4*)(table + (size_t)pos * ud + c);
-            if (P.drop.thresh != 0) {
+            if (drop.thresh != 0) {
                 float d0, d1, d2, d3;
-                bpm_drop_mult4(P.drop, i, d0, d1, d2, d3);
+                bpm_drop_mult4(drop, i, d0, d1, d2, d3);
                 v *= f32x4{d0, d1, d2, d3};
             }
             *(f32x4*)(P.out + i) = v;
@@ -220,22 +224,23 @@ __global__ void embed_pos_fwd_kernel(const Grp<EmbP> grp, const float* __restric
         const size_t row = i / d;
         const int t = (int)(row / P.B);
         const int pos = (P.x[row * d] != 0.f) ? P.pos0 + t * P.pstride + 1 : 0;     // row t sits at time pos0 + t*pstride
-        P.out[i] = (scale * P.x[i] + table[(size_t)pos * d + c]) * bpm_drop_mult(P.drop, (uint32_t)i);
+        P.out[i] = (scale * P.x[i] + table[(size_t)pos * d + c]) * bpm_drop_mult(drop, (uint32_t)i);
     }
 }
 
 __global__ void embed_pos_bwd_kernel(const Grp<EmbP> grp, int d, float scale) {
     unsigned bid = blockIdx.x, nblk;
     const EmbP& P = pick(grp, bid, nblk);      // x = dy, out = dx
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const size_t total = (size_t)P.T * P.B * d;
     if (emb_wide(P, nullptr, d, total)) {
         const uint32_t total4 = (uint32_t)(total >> 2);
         for (uint32_t q = bid * NT + threadIdx.x; q < total4; q += nblk * NT) {
             const uint32_t i = 4u * q;
             f32x4 v = scale * *(const f32x4*)(P.x + i);
-            if (P.drop.thresh != 0) {
+            if (drop.thresh != 0) {
                 float d0, d1, d2, d3;
-                bpm_drop_mult4(P.drop, i, d0, d1, d2, d3);
+                bpm_drop_mult4(drop, i, d0, d1, d2, d3);
                 v *= f32x4{d0, d1, d2, d3};
             }
             f32x4* o = (f32x4*)(P.out + i);
@@ -244,7 +249,7 @@ __global__ void embed_pos_bwd_kernel(const Grp<EmbP> grp, int d, float scale) {
         return;
     }
     for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
-        const float v = scale * P.x[i] * bpm_drop_mult(P.drop, (uint32_t)i);
+        const float v = scale * P.x[i] * bpm_drop_mult(drop, (uint32_t)i);
         P.out[i] = P.accumulate ? P.out[i] + v : v;
     }
 }
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const Grp<LnP> grp, int d) {
     __shared__ float red[3][NT / 64][512];   // 512 columns per pass
     unsigned bid = blockIdx.x, nblk;
     const LnP& P = pick(grp, bid, nblk);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wpb = NT / 64;
     const bool fused = P.cast != nullptr;          // uniform per block
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const Grp<LnP> grp, int d) {
                 const float v = av[e] + rs * (gg[e] - s1 - xh[e] * s2);
                 P.dx[(size_t)row * d + c] = v;
                 if (fused) {
-                    const float m = v * bpm_drop_mult(P.drop, (uint32_t)row * (uint32_t)d + (uint32_t)c);
+                    const float m = v * bpm_drop_mult(drop, (uint32_t)row * (uint32_t)d + (uint32_t)c);
                     put<CT>(P.cast, (size_t)row * P.ldc + c, m);
                     ac[e] += m;
                 }
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int 
     __shared__ float red[3][NT / 64][NV * 256];
     unsigned bid = blockIdx.x, nblk;
     const LnP& P = pick(grp, bid, nblk);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wpb = NT / 64;
     const int nch = d >> 2;
@@ -509,10 +516,10 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const Grp<LnP> grp, int 
                     *(f32x4*)(P.dx + (size_t)row * d + 4 * q) = v;
                     if (fused) {
                         f32x4 m = v;
-                        if (P.drop.thresh != 0) {   // row*d + 4q is a multiple of 4 (d % 4 == 0): one hash quad
+                        if (drop.thresh != 0) {   // row*d + 4q is a multiple of 4 (d % 4 == 0): one hash quad
                             float d0, d1, d2, d3;
                             const uint32_t i0 = (uint32_t)row * (uint32_t)d + 4u * (uint32_t)q;
-                            bpm_drop_mult4(P.drop, i0, d0, d1, d2, d3);
+                            bpm_drop_mult4(drop, i0, d0, d1, d2, d3);
                             m[0] *= d0; m[1] *= d1; m[2] *= d2; m[3] *= d3;
                         }
                         put4<CT>(P.cast, (size_t)row * P.ldc + 4 * q, m);
@@ -615,6 +622,7 @@ template <typename CT>
 __global__ __launch_bounds__(NT) void rows_cast_kernel(const Grp<CastP> grp) {
     unsigned bid = blockIdx.x, nblk;
     const CastP& P = pick(grp, bid, nblk);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     const int c = (bid % P.cblk) * NT + threadIdx.x;
     const int r0 = (bid / P.cblk) * CAST_ROWS;
     const int r1 = min(P.R, r0 + CAST_ROWS);
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(NT) void rows_cast_kernel(const Grp<CastP> grp) {
         if (c < P.C) {
             v = P.a_is_ct ? Tr<CT>::to_f(((const CT*)P.a)[(size_t)r * P.lda + c]) : ((const float*)P.a)[(size_t)r * P.lda + c];
             if (P.b) v += P.b[(size_t)r * P.ldb + c];
-            v *= bpm_drop_mult(P.drop, (uint32_t)r * (uint32_t)P.C + (uint32_t)c);
+            v *= bpm_drop_mult(drop, (uint32_t)r * (uint32_t)P.C + (uint32_t)c);
             if (P.df32) P.df32[(size_t)r * P.ldf + c] = v;
             s += v;
         }
@@ -740,7 +748,7 @@ template <typename P> inline bool grp_ok(int n) { return n >= 1 && n <= BPM_MAX_
 extern "C" int bpm_pack_rows_fwd(int dtype, const bpm_pack_problem* q, int n, uint64_t seed, void* stream) {
     if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
     Grp<PackP> g;
-    g.n = n; g.blk0[0] = 0;
+    g.n = n; g.blk0[0] = 0; g.seedp = bpm_seed_ptr(seed);
     for (int i = 0; i < n; ++i) {
         if (!q[i].src || !q[i].dst || q[i].B < 1 || q[i].T < 1 || q[i].C < 1 || q[i].ld < q[i].C) return BPM_ERR_ARG;
         PackP& p = g.p[i];
@@ -757,7 +765,7 @@ extern "C" int bpm_pack_rows_fwd(int dtype, const bpm_pack_problem* q, int n, ui
 extern "C" int bpm_pack_rows_bwd(const bpm_pack_problem* q, int n, uint64_t seed, void* stream) {
     if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
     Grp<PackP> g;
-    g.n = n; g.blk0[0] = 0;
+    g.n = n; g.blk0[0] = 0; g.seedp = bpm_seed_ptr(seed);
     for (int i = 0; i < n; ++i) {
         if (!q[i].g || !q[i].dsrc || q[i].B < 1 || q[i].T < 1 || q[i].C < 1 || q[i].ldg < q[i].C) return BPM_ERR_ARG;
         PackP& p = g.p[i];
@@ -780,7 +788,7 @@ extern "C" int bpm_pack_weights(int dtype, const bpm_pack_desc* table_dev, int n
 
 static int fill_embed(Grp<EmbP>& g, const bpm_embed_problem* q, int n, int d, uint64_t seed) {
     if (!q || n < 1 || n > BPM_MAX_GROUP || d < 1) return BPM_ERR_ARG;
-    g.n = n; g.blk0[0] = 0;
+    g.n = n; g.blk0[0] = 0; g.seedp = bpm_seed_ptr(seed);
     for (int i = 0; i < n; ++i) {
         if (!q[i].x || !q[i].out || q[i].T < 1 || q[i].B < 1) return BPM_ERR_ARG;
         EmbP& p = g.p[i];
@@ -864,7 +872,7 @@ extern "C" int bpm_embed_pos_bwd(const bpm_embed_problem* q, int n, int d, float
 
 static int fill_ln(Grp<LnP>& g, const bpm_ln_problem* q, int n, int d, bool bwd, int* span, uint64_t seed = 0) {
     if (!q || n < 1 || n > BPM_MAX_GROUP || d < 1 || d > 64 * MAXE) return BPM_ERR_ARG;
-    g.n = n; g.blk0[0] = 0;
+    g.n = n; g.blk0[0] = 0; g.seedp = bpm_seed_ptr(seed);
     *span = d;
     for (int i = 0; i < n; ++i) {
         const bpm_ln_problem& s = q[i];
@@ -1005,7 +1013,7 @@ extern "C" int bpm_ln_bwd(int dtype, const bpm_ln_problem* q, int n, int d, uint
 extern "C" int bpm_rows_cast(int dtype, const bpm_cast_problem* q, int n, uint64_t seed, void* stream) {
     if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
     Grp<CastP> g;
-    g.n = n; g.blk0[0] = 0;
+    g.n = n; g.blk0[0] = 0; g.seedp = bpm_seed_ptr(seed);
     for (int i = 0; i < n; ++i) {
         const bpm_cast_problem& s = q[i];
         if (!s.a || s.R < 1 || s.C < 1 || s.lda < s.C || (s.b && s.ldb < s.C) || (s.dst_ct && s.ldd < s.C) ||
@@ -1043,7 +1051,7 @@ extern "C" int bpm_rows_cast(int dtype, const bpm_cast_problem* q, int n, uint64
 
 static int fill_gmu(Grp<GmuP>& g, const bpm_gmu_problem* q, int n, int d, bool bwd) {
     if (!q || n < 1 || n > BPM_MAX_GROUP || d < 1) return BPM_ERR_ARG;
-    g.n = n; g.blk0[0] = 0;
+    g.n = n; g.blk0[0] = 0; g.seedp = nullptr;
     for (int i = 0; i < n; ++i) {
         const bpm_gmu_problem& s = q[i];
         if (!s.a1 || !s.a2 || !s.ag || !s.x1 || !s.x2 || s.R < 1) return BPM_ERR_ARG;

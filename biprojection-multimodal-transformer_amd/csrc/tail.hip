@@ -29,7 +29,7 @@ struct LinP {                              // out[b, j] = act(sum_k W[j, k] in[b
     DropCfg drop;
     int col0;                              // first global column index (blocks are dealt over all problems)
 };
-struct LinGrp { int n, B, total_cols; LinP p[8]; };
+struct LinGrp { const uint64_t* seedp; int n, B, total_cols; LinP p[8]; };
 
 // forward skinny product: one wave per output column, lanes over k
 __global__ __launch_bounds__(TNT) void tail_linear_kernel(const LinGrp g) {
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(TNT) void tail_linear_kernel(const LinGrp g) {
     for (int i = 1; i < g.n; ++i)
         if (col >= g.p[i].col0) pi = i;
     const LinP& P = g.p[pi];
+    const DropCfg drop = bpm_resolve_drop(P.drop, g.seedp);
     const int j = col - P.col0;
     const float* w = P.W + (size_t)j * P.ldw;
     for (int b0 = 0; b0 < g.B; b0 += BC) {
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(TNT) void tail_linear_kernel(const LinGrp g) {
             if (P.bias) v += P.bias[j];
             if (P.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
             else if (P.act == ACT_TANH) v = tanhf(v);
-            else if (P.act == ACT_RELU_DROP) v = fmaxf(v, 0.f) * bpm_drop_mult(P.drop, (uint32_t)b * (uint32_t)P.N + (uint32_t)j);
+            else if (P.act == ACT_RELU_DROP) v = fmaxf(v, 0.f) * bpm_drop_mult(drop, (uint32_t)b * (uint32_t)P.N + (uint32_t)j);
             if (P.resid) v += P.resid[(size_t)b * P.ldr + j];
             P.out[(size_t)b * P.ldo + j] = v;
         }
@@ -298,7 +299,9 @@ extern "C" int bpm_tail_fwd(const bpm_tail_desc* t, uint64_t seed, void* stream)
     g.n = 1;
     g.p[0] = lin(t->W1, d, t->h, d, t->b1, t->p1, d, d, d, ACT_RELU_DROP);
     g.p[0].drop = bpm_make_drop(t->out_dropout, seed, t->drop_site);
+    g.seedp = bpm_seed_ptr(seed);
     if ((rc = launch_linear(g, s))) return rc;
+    g.seedp = nullptr;
     g.p[0] = lin(t->W2, d, t->p1, d, t->b2, t->y, d, d, d, ACT_NONE);
     g.p[0].resid = t->h; g.p[0].ldr = d;
     if ((rc = launch_linear(g, s))) return rc;

@@ -34,7 +34,7 @@ import torch
 from . import ops
 from ._lib import (BPM_BF16, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
                    AttnProblem, CastProblem, FoldDesc, GemmProblem, LnProblem, PackDesc,
-                   UnfoldDesc, XBlockProblem)
+                   UnfoldDesc)
 from .ops import pad32
 
 # dropout site ids (unique per encoder / layer / op; the seed changes per step)
@@ -149,12 +149,15 @@ class ParamStore:
                 return p.grad is None
         return True
 
-    def prezero(self) -> None:
+    def prezero(self, force: bool = False) -> None:
         """Called at the start of a training forward: if the gradients are unset now (the usual zero_grad /
         `p.grad = None` step), clear the flat gradient buffer on the side stream while the forward pass runs, instead
-        of on the critical path when backward starts."""
+        of on the critical path when backward starts.  force: clear it in any case (a captured forward graph whose key
+        says the gradients start from zero), on the current stream when there is no side stream."""
         self._prezero_ev = None
-        if self._fresh() and _SIDE:
+        if not (force or self._fresh()):
+            return
+        if _SIDE:
             main = torch.cuda.current_stream()
             side = _side_stream(main.device, 1, self.side_low)
             side.wait_stream(main)                      # the previous step's consumers of gflat (optimizer, all-reduce)
@@ -162,6 +165,8 @@ class ParamStore:
                 self.gflat.zero_()
             self._prezero_ev = torch.cuda.Event()
             self._prezero_ev.record(side)
+        elif force:
+            self.gflat.zero_()
 
     def begin_backward(self) -> None:
         """Gradients accumulate into gflat like autograd accumulates into .grad:
@@ -169,6 +174,10 @@ class ParamStore:
         fresh = self._fresh()
         ev = getattr(self, "_prezero_ev", None)
         self._prezero_ev = None
+        if getattr(self, "_prezeroed", False):          # cleared by a captured forward graph (models/bpmult.py), same stream
+            self._prezeroed = False
+            if fresh:
+                return
         if fresh and ev is not None:
             torch.cuda.current_stream().wait_event(ev)  # already cleared during the forward pass
         elif fresh:
@@ -312,13 +321,6 @@ class GroupCfg:
 
 
 SIDE, JOIN, MARK, WAIT, SIDE2 = "side", "join", "mark", "wait", "side2"
-# Short sequences (T, S <= 64) at head_dim 128 in bf16: the crossmodal attention block of a layer (Q / K / V
-# projections, attention, output projection + residual) CAN run as ONE launch (csrc/xblock.hip) instead of five.
-# Off by default: measured on MI355X at the kernel point (d=768, H=6, T=S=50, B=64, six encoders; tools/kernel_point.py)
-# the fused launch takes 464 us against 216 us for the separate kernels -- one 64-row workgroup per (encoder, batch
-# element) issues six LDS-DMA instructions per 16 MFMAs and is paced by their issue cost, where the grouped GEMMs spread
-# the same weight traffic over 3200-row problems.  tools/kernel_point.py and the tests flip it.
-FUSE_SHORT_BLOCKS = False
 _SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
 # dK/dV attention pass: "0" main stream, "1" side stream, "2" a third stream, "auto": side stream at hidden >= 512.
 # dK / dV feed only side-stream work (weight gradients, key/value dgrad).  At hidden 300 the side stream is the longer
@@ -330,6 +332,8 @@ _side_streams: Dict[Tuple[int, int, bool], "torch.cuda.Stream"] = {}
 # 768 every GEMM workgroup owns a CU for 50-300 us, the side stream's weight gradients are a third of the step's work,
 # and starving them only lengthens the tail (37.97 ms/step low, 37.53 normal).
 _SIDE_PRIORITY_ENV = os.environ.get("BPMULT_SIDE_PRIORITY", "auto")
+# (Measured in round 3 and removed: a side stream restricted to 160-224 CUs by hipExtStreamCreateWithCUMask, so that the
+# main stream's row kernels never queue behind weight-gradient workgroups: 47-51 ms/step against 32.5.)
 
 
 def _side_stream(device, which: int = 1, low: bool = True) -> "torch.cuda.Stream":
@@ -456,8 +460,6 @@ class EncoderGroupPlan:
         self._dkv_side = _DKV_SIDE_ENV if _DKV_SIDE_ENV != "auto" else ("1" if d >= 512 else "0")
         self._side_low = d < 512
         self.store.side_low = self._side_low
-        self.fused_block = (FUSE_SHORT_BLOCKS and self.dtype == BPM_BF16 and self.dh == 128 and self.ld == d
-                            and all(e.T <= 64 and e.S <= 64 and e.T_full is None for e in self.encs))
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
         self._bwd = {True: self._build_bwd(True), False: self._build_bwd(False)}
 
@@ -490,7 +492,7 @@ class EncoderGroupPlan:
         steps, kv_steps = [], [(SIDE, (ops.ln_fwd, self.dtype, A(LnProblem, hat), d)), (MARK, "hat")]
         for i in range(c.layers):
             ln, qkv, att, outp, ln2, fc1, fc2 = [], [], [], [], [], [], []
-            kvp, xblk = [], []
+            kvp = []
             pre = dict(ln=[], qkv=[], att=[], outp=[], cast=[])      # biprojection self-attention half
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -533,14 +535,6 @@ class EncoderGroupPlan:
                     q_src, resid_src = b["xn"][i], x_in
                     gf, bf = g1, b1
                     stf = (b["st1m"][i], b["st1r"][i])
-                if self.fused_block:
-                    kvf = self._pn(e, i, KVF)
-                    xblk.append(ops.xblock_problem(
-                        q_src, b["khat"], b["vhat"], st.sptr(ipw, 0), ipb[:d], st.sptr(kvf, 0), st.fold(kvf, 0, d),
-                        st.sptr(kvf, d * ld), st.fold(kvf, d, d), st.sptr(wo), P("self_attn.out_proj.bias"), resid_src, b["xmid"][i],
-                        b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, d, ld,
-                        self._mask_off(e.T, e.S), self.scale, attn_drop=pr(e.attn_dropout), attn_site=site(e.enc_id, i, S_ATTN),
-                        res_drop=pr(c.res_dropout), res_site=site(e.enc_id, i, S_RES1)))
                 qkv.append(proj(q_src, R, 0, b["qh"][i], e.T))
                 kvp.append(proj_kv(b["khat"], 1, b["kh"][i]))
                 kvp.append(proj_kv(b["vhat"], 2, b["vh"][i]))
@@ -565,17 +559,13 @@ class EncoderGroupPlan:
                           (ops.rows_cast, self.dtype, A(CastProblem, pre["cast"]))]
             # K/V side of every layer depends only on the (embedded) key/value sources: the side stream runs it
             # ahead of the query chain; the main stream waits for layer i's K/V heads just before attention i.
-            if not self.fused_block:
-                kv_steps += [(SIDE, self._gemm(GEMM_NT, kvp)), (MARK, i)]
+            kv_steps += [(SIDE, self._gemm(GEMM_NT, kvp)), (MARK, i)]
             if ln:
                 steps.append((ops.ln_fwd, self.dtype, A(LnProblem, ln), d))
-            if self.fused_block:       # one launch: projections + attention + output projection + residual
-                steps += [(WAIT, "hat"), (ops.xblock_fwd, self.dtype, A(XBlockProblem, xblk))]
-            else:
-                steps += [self._gemm(GEMM_NT, qkv),
-                          (WAIT, i),
-                          (ops.attn_fwd, self.dtype, A(AttnProblem, att)),
-                          self._gemm(GEMM_NT, outp)]
+            steps += [self._gemm(GEMM_NT, qkv),
+                      (WAIT, i),
+                      (ops.attn_fwd, self.dtype, A(AttnProblem, att)),
+                      self._gemm(GEMM_NT, outp)]
             steps += [(ops.ln_fwd, self.dtype, A(LnProblem, ln2), d),
                       self._gemm(GEMM_NT, fc1),
                       self._gemm(GEMM_NT, fc2)]
@@ -589,7 +579,7 @@ class EncoderGroupPlan:
         fn = s[0]
         if fn is ops.gemm_grouped:
             fn(s[1], s[2], s[3], seed)
-        elif fn in (ops.attn_fwd, ops.attn_bwd, ops.attn_bwd_dq, ops.attn_bwd_dkv, ops.rows_cast, ops.xblock_fwd):
+        elif fn in (ops.attn_fwd, ops.attn_bwd, ops.attn_bwd_dq, ops.attn_bwd_dkv, ops.rows_cast):
             fn(s[1], s[2], seed)
         elif fn is ops.ln_fwd:
             fn(s[1], s[2], s[3])
@@ -677,8 +667,8 @@ class EncoderGroupPlan:
                     ops.embed_problem(k, b["ke"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_K)),
                     ops.embed_problem(v, b["ve"], e.S, B, drop_p=p, drop_site=site(e.enc_id, 0, S_EMB_V))]
         ops.embed_pos_fwd(emb, self.table, d, math.sqrt(d), seed)
-        self._run(self._fwd[training], seed)
         self._last = (seed, training)
+        self._run(self._fwd[training], seed)
         return [b["out"] for b in self.buf]
 
     # -- backward tables --------------------------------------------------------

@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from .. import config, ops
-from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, CastProblem, GemmProblem, GmuProblem, TailDesc, TailGrads
+from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, SEED_INDIRECT, CastProblem, GemmProblem, GmuProblem, TailDesc, TailGrads
 from ..engine import SITE_TEXT, EncoderDesc, EncoderGroupPlan, GroupCfg, ParamStore, register_encoder_shadows
 from ..ops import pad32
 from .encoder import TransformerEncoder
@@ -341,10 +341,15 @@ class _Trunk:
         ops.gemm_grouped(self.dtype, GEMM_NN, dg2, 0)
 
     # -- whole trunk ------------------------------------------------------------------
-    def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> List[torch.Tensor]:
-        self.st.refresh_shadows()
-        if training and getattr(self.m, "_want_grad", False):
-            self.st.prezero()
+    def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool, prezero: Optional[bool] = None) -> List[torch.Tensor]:
+        """The caller has refreshed the weight shadows (ParamStore.refresh_shadows: a host-side decision, so it stays
+        outside a captured graph).  prezero: clear the flat gradient buffer on the side stream beside the forward pass
+        (None: when a backward will follow and the gradients are unset)."""
+        if prezero is None:
+            if training and getattr(self.m, "_want_grad", False):
+                self.st.prezero()
+        elif prezero:
+            self.st.prezero(force=True)
         self.conv_forward(feats, seed, training)
         px = self.px
         q1 = [px[q] for (q, kv, _) in LEVEL1.values()]
@@ -413,11 +418,13 @@ class _Trunk:
         ops.tail_bwd(self._tail_desc, gr)
         return grads, tl["dextra"]
 
-    def backward(self, grads: Optional[Sequence[Optional[torch.Tensor]]], seed: int, need_dx: Dict[str, bool]):
+    def backward(self, grads: Optional[Sequence[Optional[torch.Tensor]]], seed: int, need_dx: Dict[str, bool], begin: bool = True):
         """grads: d(top_l), d(mid_l), d(top_a), d(mid_a), d(top_v), d(mid_v); None: the `dout` buffers of the GMU units
-        already hold them (written by tail_backward)."""
+        already hold them (written by tail_backward).  begin=False: the caller has dealt with the state of the flat
+        gradient buffer (captured graphs)."""
         st = self.st
-        st.begin_backward()
+        if begin:
+            st.begin_backward()
         it = iter(grads) if grads is not None else None
         for t in ("l", "a", "v"):
             for k in ("top", "mid"):
@@ -469,8 +476,90 @@ class _Trunk:
                 self.dpx[k].index_add_(0, self.idx[k], gq)
         res = self.conv_backward(seed, need_dx)
         self._ready("proj")
-        st.end_backward()
+        if begin:
+            st.end_backward()
         return res
+
+    # -- captured launch sequences (hipGraph) ---------------------------------------
+    # The ~420 launches of a step are the same every step for a given (mode, input lengths): captured once per key and
+    # replayed.  What changes per step travels through device memory: the inputs (copied into static staging tensors),
+    # the dropout seed (BPM_SEED_INDIRECT: the kernels read it when they run) and the incoming logit gradients.
+    # Host-side decisions stay outside the graph: the weight-shadow refresh, whether the gradients start from zero
+    # (part of the key), attaching .grad views.  Used when nothing needs the eager launch order: no gradient-exchange
+    # hook (GradSync runs eagerly: its all-reduces interleave with backward), launch profiler off.
+    GRAPH_WARMUP = 2            # eager runs of a key before it is captured (lazy allocations, stream creation)
+
+    def _seed_handle(self, seed: int) -> int:
+        if getattr(self, "_seed_dev", None) is None:
+            self._seed_dev = torch.zeros(1, device=self.st.device, dtype=torch.int64)
+        self._seed_dev.fill_(seed)
+        return SEED_INDIRECT | self._seed_dev.data_ptr()
+
+    def graph_forward(self, feats: Dict[str, torch.Tensor], extra: Optional[torch.Tensor], seed: int, training: bool, want_grad: bool):
+        """Forward pass through a captured graph when one exists (or can be captured now) for this key; returns
+        (logits, z, key) or None (the caller then runs eagerly)."""
+        fresh = bool(want_grad and training and self.st._fresh())
+        key = (training, fresh, tuple(tuple(feats[k].shape) for k in ("l", "v", "a")), extra is not None)
+        if getattr(self, "_fg", None) is None:
+            self._fg, self._bg, self._gpool = {}, {}, torch.cuda.graph_pool_handle()
+        ent = self._fg.setdefault(key, {"calls": 0})
+        ent["calls"] += 1
+        if "graph" not in ent:
+            if ent["calls"] <= self.GRAPH_WARMUP:
+                return None
+            ent["in"] = {k: torch.empty_like(feats[k]) for k in ("l", "v", "a")}
+            ent["extra"] = torch.empty_like(extra) if extra is not None else None
+            handle = self._seed_handle(seed)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._gpool):
+                self.forward(ent["in"], handle, training, prezero=fresh)
+                self.st._prezero_ev = None                    # (an event recorded while capturing means nothing outside)
+                ent["out"] = self.tail_forward(ent["extra"], handle, training)
+            ent["graph"] = g
+            # host-side state a forward leaves for its backward (a replay runs no Python): restored before the backward
+            ent["state"] = (self._conv, self._tail_desc, self.plan1._last, self.plan2._last)
+        for k in ("l", "v", "a"):
+            ent["in"][k].copy_(feats[k])
+        if extra is not None:
+            ent["extra"].copy_(extra)
+        self._seed_handle(seed)
+        ent["graph"].replay()
+        return ent["out"][0], ent["out"][1], key
+
+    def restore_forward_state(self, fkey) -> None:
+        """Before the backward (captured or eager) of a forward that was a graph replay."""
+        self._conv, self._tail_desc, self.plan1._last, self.plan2._last = self._fg[fkey]["state"]
+
+    def graph_backward(self, fkey, dlogits: torch.Tensor, dz: Optional[torch.Tensor], params, seed: int, need: Dict[str, bool]):
+        """Backward of a graph-run forward.  The flat gradient buffer was cleared by that forward graph when the
+        gradients were unset (fkey[1]); otherwise this pass accumulates.  Returns (parameter gradients of the tail,
+        d(extra), d(features)) as clones of the graph's static outputs, or None before the key is captured."""
+        fresh = fkey[1]
+        self.restore_forward_state(fkey)
+        if fresh != self.st._fresh():
+            return None                                       # .grad was attached / detached between forward and backward
+        key = (fkey, dz is not None, tuple(sorted(k for k, v in need.items() if v)))
+        ent = self._bg.setdefault(key, {"calls": 0})
+        ent["calls"] += 1
+        if "graph" not in ent:
+            if ent["calls"] <= 1:
+                return None
+            ent["dlogits"] = torch.empty_like(dlogits)
+            ent["dz"] = torch.empty_like(dz) if dz is not None else None
+            handle = self._seed_handle(seed)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._gpool):
+                pg, dextra = self.tail_backward(ent["dlogits"], ent["dz"], params)
+                res = self.backward(None, handle, need, begin=False)
+            ent.update(graph=g, pg=pg, dextra=dextra, res=res)
+        ent["dlogits"].copy_(dlogits)
+        if dz is not None:
+            ent["dz"].copy_(dz)
+        self._seed_handle(seed)
+        ent["graph"].replay()
+        self.st.end_backward()
+        res = {k: (v.clone() if v is not None else None) for k, v in ent["res"].items()}
+        return [t.clone() for t in ent["pg"]], ent["dextra"], res
 
     def _ready(self, section: str, events=None) -> None:
         hook = getattr(self.m, "_grad_ready_hook", None)
@@ -501,9 +590,15 @@ class _ModelFn(torch.autograd.Function):
         trunk = model._trunk_for(x_l.shape[0])
         seed = model._next_seed()
         feats = {"l": x_l.detach().contiguous(), "v": x_v.detach().contiguous(), "a": x_a.detach().contiguous()}
-        trunk.forward(feats, seed, model.training)
         ex = extra.detach().contiguous() if extra is not None else None
-        logits, z = trunk.tail_forward(ex, seed, model.training)
+        trunk.st.refresh_shadows()
+        ran = trunk.graph_forward(feats, ex, seed, model.training, model._want_grad) if model._graphs_on() else None
+        if ran is None:
+            trunk.forward(feats, seed, model.training)
+            logits, z = trunk.tail_forward(ex, seed, model.training)
+            ctx.fkey = None
+        else:
+            logits, z, ctx.fkey = ran
         trunk.stamp = getattr(trunk, "stamp", 0) + 1
         ctx.trunk, ctx.seed, ctx.stamp, ctx.extra, ctx.params = trunk, seed, trunk.stamp, ex, tail_params
         ctx.need = {"l": x_l.requires_grad, "v": x_v.requires_grad, "a": x_a.requires_grad}
@@ -517,8 +612,16 @@ class _ModelFn(torch.autograd.Function):
                                "batch size) has overwritten; run forward -> backward one step at a time")
         dlogits = dlogits.contiguous().float()
         dz = dz.contiguous().float() if dz is not None else None
-        pgrads, dextra = ctx.trunk.tail_backward(dlogits, dz, ctx.params)
-        res = ctx.trunk.backward(None, ctx.seed, ctx.need)
+        ran = ctx.trunk.graph_backward(ctx.fkey, dlogits, dz, ctx.params, ctx.seed, ctx.need) if ctx.fkey is not None else None
+        if ran is not None:
+            pgrads, dextra, res = ran
+        else:
+            if ctx.fkey is not None and ctx.fkey[1]:
+                if not ctx.trunk.st._fresh():
+                    raise RuntimeError("gradients were attached between forward and backward of one step")
+                ctx.trunk.st._prezeroed = True            # the forward GRAPH cleared the flat gradient buffer
+            pgrads, dextra = ctx.trunk.tail_backward(dlogits, dz, ctx.params)
+            res = ctx.trunk.backward(None, ctx.seed, ctx.need)
         return (None, res["l"], res["v"], res["a"], dextra.clone() if (dextra is not None and ctx.extra is not None) else None,
                 None) + tuple(pgrads)
 
@@ -659,7 +762,17 @@ class _BPMulTBase(nn.Module):
         replay the mask sequence from step 1."""
         self.dropout_step += 1
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
-        return (torch.initial_seed() * 1000003 + rank * 0x9E3779B97F4A7C15 + int(self.dropout_step)) & 0xFFFFFFFFFFFFFFFF
+        return (torch.initial_seed() * 1000003 + rank * 0x9E3779B97F4A7C15 + int(self.dropout_step)) & 0x7FFFFFFFFFFFFFFF   # 63 bits: bit 63 marks an indirect seed
+
+    def _graphs_on(self) -> bool:
+        """Captured-graph replay of the step (see _Trunk.graph_forward): on unless switched off (`use_graphs`,
+        BPMULT_GRAPH=0), a gradient-exchange hook needs the eager launch order, or the launch profiler is recording."""
+        if not getattr(self, "use_graphs", True) or os.environ.get("BPMULT_GRAPH", "1") == "0":
+            return False
+        if getattr(self, "_grad_ready_hook", None) is not None:
+            return False
+        from .. import _lib
+        return not _lib.prof_enabled()
 
     def tail_parameters(self):
         """The [B,d] tail's parameters in the order bpm_tail_bwd's gradients are returned."""

@@ -295,26 +295,3 @@ def tail_fwd(desc, seed: int = 0) -> None:
 
 def tail_bwd(desc, grads) -> None:
     _lib.check(_lib.lib().bpm_tail_bwd(C.byref(desc), C.byref(grads), _stream()), "bpm_tail_bwd")
-
-
-# ----------------------------------------------------------------------------
-# fused crossmodal-attention block (T, S <= 64, head_dim 128, bf16)
-# ----------------------------------------------------------------------------
-def xblock_problem(xq, xk, xv, Wq, bq, Wk, bk, Wv, bv, Wo, bo, resid, out, qh, kh, vh, ao, ldo, lse, B, H, T, S, d, ld, mask_off,
-                   scale, attn_drop=0.0, attn_site=0, res_drop=0.0, res_site=0) -> "_lib.XBlockProblem":
-    p = _lib.XBlockProblem()
-    p.xq, p.xk, p.xv = _p(xq), _p(xk), _p(xv)
-    p.Wq, p.Wk, p.Wv, p.Wo = (w if isinstance(w, int) else _p(w) for w in (Wq, Wk, Wv, Wo))
-    p.bq, p.bk, p.bv, p.bo = (_f32(b_, "xblock bias") for b_ in (bq, bk, bv, bo))
-    p.resid, p.out = _f32(resid, "resid"), _f32(out, "out")
-    p.qh, p.kh, p.vh, p.ao, p.ldo, p.lse = _p(qh), _p(kh), _p(vh), _p(ao), ldo, _f32(lse, "lse")
-    p.B, p.H, p.T, p.S, p.d, p.ld, p.mask_off, p.scale = B, H, T, S, d, ld, mask_off, scale
-    p.attn_drop, p.attn_site, p.res_drop, p.res_site = attn_drop, attn_site, res_drop, res_site
-    return p
-
-
-def xblock_fwd(dtype: int, probs, seed: int = 0) -> None:
-    arr = _as_array(_lib.XBlockProblem, probs)
-    L, s = _lib.lib(), _stream()
-    for sub, k in _chunks(arr, _lib.XBlockProblem, None):
-        _lib.check(L.bpm_xblock_fwd(dtype, sub, k, seed, s), "bpm_xblock_fwd")

@@ -20,7 +20,12 @@
  *    multiple of 32 elements and ZERO padding columns; residual-stream tensors
  *    are fp32 [(t*B + b), d] exactly as torch lays out [T,B,d];
  *  - dropout masks are a pure function of (seed, site, element index)
- *    (counter hash), so backward regenerates them; drop_p = 0 disables.
+ *    (counter hash), so backward regenerates them; drop_p = 0 disables;
+ *  - every `seed` argument is either a 63-bit value or BPM_SEED_INDIRECT |
+ *    the address of a device uint64 that the kernels read WHEN THEY RUN: a
+ *    launch sequence captured once into a hipGraph then replays with a fresh
+ *    seed per step (the host stores it before each replay).  Both forms draw
+ *    identical masks for the same seed value.
  */
 #ifndef BPMULT_HIP_H
 #define BPMULT_HIP_H
@@ -33,6 +38,7 @@ extern "C" {
 #endif
 
 #define BPM_ABI_VERSION 1
+#define BPM_SEED_INDIRECT (1ull << 63) /* seed = BPM_SEED_INDIRECT | (uintptr_t)device pointer to the uint64 seed */
 #define BPM_MAX_GROUP 18 /* problems per grouped launch (6 encoders of a level x 3 projections) */
 #define BPM_GEMM_MAX_GROUP 24 /* bpm_gemm_grouped alone: 6 encoders x (q, k, v, out) weight gradients in one launch */
 
@@ -262,26 +268,6 @@ typedef struct bpm_gmu_problem {
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
-/* Fused crossmodal-attention block, forward, for short sequences: T, S <= 64, head_dim 128 (d = 128 H), BPM_BF16 only
- * (anything else: BPM_ERR_ARG -- run the separate kernels).  One launch replaces Q / K / V projections + attention +
- * output projection (multihead_attention.py:82-130 with the residual dropout + add of transformer.py:157-175):
- *   Q = (xq Wq^T + bq) scale, K = xk Wk^T + bk, V = xv Wv^T + bv, O = dropout(softmax_fp32(Q_h K_h^T + mask)) V_h,
- *   out = resid + dropout(O Wo^T + bo).
- * xq [T*B, ld] is the normalised query source, xk / xv [S*B, ld] the normalised key / value sources (CT = bf16, rows
- * t*B + b, ld == d); Wq / Wk / Wv / Wo are CT [d, ld] (LayerNorm gain / bias of the key / value side folded in by the
- * caller), biases fp32 [d].  Saved for the backward kernels exactly as the separate path saves them: qh [B,H,T,128],
- * kh / vh [B,H,S,128], ao [T*B, ldo] (ldo == ld), lse [B,H,T].  Key j is visible to query i iff j - i < mask_off. */
-typedef struct bpm_xblock_problem {
-    const void* xq; const void* xk; const void* xv;
-    const void* Wq; const float* bq; const void* Wk; const float* bk; const void* Wv; const float* bv; const void* Wo; const float* bo;
-    const float* resid; float* out;
-    void* qh; void* kh; void* vh; void* ao; int ldo; float* lse;
-    int B, H, T, S, d, ld, mask_off;
-    float scale;
-    float attn_drop; uint32_t attn_site; float res_drop; uint32_t res_site;
-} bpm_xblock_problem;
-int bpm_xblock_fwd(int dtype, const bpm_xblock_problem* probs, int n, uint64_t seed, void* stream);
-
 /* Front-end: AudioEncoder of the 4-modal model (mmtr.py:93-108: Conv1d(96,96,k=128,stride 2) x 2 + AdaptiveAvgPool1d(200)).
  * A convolution is computed as a product over window rows with bpm_gemm_grouped:
  *   col[(b,l), ci*K + k] = x[b*sb + ci*sc + (stride*l + k)*sl]      (bpm_im2col1d; x fp32 with element strides, col CT [B*Lout, ldcol])
@@ -350,7 +336,7 @@ int bpm_stream_priority_range(int* least, int* greatest);
  * per-launch durations (ms), work and launch count of one kind, and clears them.
  * ---------------------------------------------------------------------- */
 enum { BPM_PROF_GEMM_NT = 0, BPM_PROF_GEMM_NN = 1, BPM_PROF_GEMM_TN = 2, BPM_PROF_ATTN_FWD = 3,
-       BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5, BPM_PROF_XBLOCK = 6 };
+       BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5 };
 int bpm_prof_enable(unsigned kind_mask);
 int bpm_prof_collect(int kind, double* total_ms, double* total_work, int* launches);
 /* The same, plus the launches' ALGORITHMIC HBM bytes (GEMM: both operands once, the output once, every side operand of

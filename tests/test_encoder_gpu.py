@@ -81,38 +81,3 @@ def test_state_dict_keys_match_reference_layout():
         assert k in keys
     assert enc.state_dict()["layers.0.self_attn.in_proj_weight"].shape == (72, 24)
 
-
-@pytest.mark.parametrize("bi,Tn,S", [(False, 50, 50), (False, 33, 64), (True, 40, 21)])
-def test_fused_short_block_schedule_equals_separate_kernels(bi, Tn, S):
-    """engine.FUSE_SHORT_BLOCKS: with T, S <= 64 and head_dim 128 (bf16) the crossmodal attention block of every layer
-    runs as one bpm_xblock_fwd launch that also writes what the (unchanged) backward kernels read.  Same weights, inputs
-    and dropout seed through both schedules: outputs and every gradient must agree to bf16 rounding of re-ordered sums."""
-    from bpmult_amd import engine
-    d, H, B, Ly = 256, 2, 3, 2
-    res = []
-    for fuse in (False, True):
-        engine.FUSE_SHORT_BLOCKS = fuse
-        try:
-            torch.manual_seed(11)
-            enc = TransformerEncoder(d, H, Ly, attn_dropout=0.1, relu_dropout=0.1, res_dropout=0.1, embed_dropout=0.1, attn_mask=True,
-                                     biprojection=bi)
-            enc.precision = "bf16"
-            with torch.no_grad():
-                for k, p in enc.named_parameters():
-                    p.copy_(T(det_param("fz." + k, p.shape)))
-            enc = enc.cuda().train()
-            x = T(det("fz.x", (Tn, B, d))).cuda().requires_grad_(True)
-            kv = T(det("fz.kv", (S, B, d))).cuda().requires_grad_(True)
-            y = enc(x, kv, kv)
-            plan = next(iter(enc._plans.values()))
-            assert plan.fused_block == fuse
-            (y * T(det("fz.w", tuple(y.shape))).cuda()).sum().backward()
-            res.append((y.detach().float().cpu(), x.grad.float().cpu(), kv.grad.float().cpu(),
-                        {k: p.grad.float().cpu() for k, p in enc.named_parameters()}))
-        finally:
-            engine.FUSE_SHORT_BLOCKS = False
-    (y0, gx0, gk0, gp0), (y1, gx1, gk1, gp1) = res
-    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-9))
-    assert rel(y1, y0) < 2e-2 and rel(gx1, gx0) < 5e-2 and rel(gk1, gk0) < 5e-2, (rel(y1, y0), rel(gx1, gx0), rel(gk1, gk0))
-    for k in gp0:
-        assert rel(gp1[k], gp0[k]) < 8e-2, (k, rel(gp1[k], gp0[k]))

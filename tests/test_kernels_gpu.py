@@ -539,6 +539,87 @@ def test_gemm_operand_column_view_at_the_end_of_its_allocation(dtype, variant, M
     close(out, ref, tol(dtype) if dtype == BPM_F32 else 2e-3, f"column-view operand, variant {variant}")
 
 
+def test_indirect_seed_draws_the_same_masks():
+    """BPM_SEED_INDIRECT | device pointer (the seed is read by the kernels when they run: captured graphs) == the same
+    seed passed by value, for every kernel family with a dropout site: GEMM epilogues (tiled and LDS-DMA kernels),
+    attention forward / backward, LayerNorm backward's fused cast, rows_cast, embed_pos, pack_rows."""
+    from bpmult_amd._lib import SEED_INDIRECT
+    from bpmult_amd.ops import F_KPAD
+    dtype, seed = BPM_BF16, 0x1234_5678_9ABC_DEF
+    sd = torch.tensor([seed], dtype=torch.int64, device=DEV)
+    ind = SEED_INDIRECT | sd.data_ptr()
+
+    def both(fn):
+        outs = []
+        for s in (seed, ind):
+            outs.append(fn(s))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        return outs[0]
+
+    for (M, N, K) in ((200, 96, 64), (1024, 768, 768)):          # tiled kernel, LDS-DMA kernel
+        A, _ = to_ct(rnd(M, K, seed=1), dtype)
+        W, _ = to_ct(rnd(N, K, seed=2, scale=K ** -0.5), dtype)
+
+        def gemm(s):
+            out = torch.zeros(M, N, device=DEV)
+            ops.gemm_grouped(dtype, GEMM_NT, [ops.gemm_problem(A, W, out, M, N, K, A.shape[1], W.shape[1], N, drop_p=0.3, drop_site=5, flags=F_KPAD)], s)
+            return [out]
+        o = both(gemm)[0]
+        assert 0.2 < float((o == 0).float().mean()) < 0.4
+
+    B, H, T, S, dh, dhp = 2, 2, 70, 90, 64, 64
+    q, k, v, do = (torch.randn(B, H, n, dhp, device=DEV).to(torch.bfloat16) for n in (T, S, S, T))
+
+    def attn(s):
+        o = torch.zeros(T * B, H * dhp, device=DEV, dtype=torch.bfloat16)
+        lse, delta = torch.zeros(B, H, T, device=DEV), torch.zeros(B, H, T, device=DEV)
+        dq, dk, dv = (torch.zeros(n * B, H * dhp, device=DEV, dtype=torch.bfloat16) for n in (T, S, S))
+        p = ops.attn_problem(q, k, v, o, H * dhp, lse, B, H, T, S, dh, dhp, 1 + abs(S - T), dO=do, delta=delta, dQ=dq, lddq=H * dhp,
+                             dK=dk, lddk=H * dhp, dV=dv, lddv=H * dhp, dq_scale=0.125, drop_p=0.2, drop_site=9)
+        ops.attn_fwd(dtype, [p], s)
+        ops.attn_bwd(dtype, [p], s)
+        return [o, dq, dk, dv]
+    both(attn)
+
+    R, d = 300, 768
+    x, dy = torch.randn(R, d, device=DEV), torch.randn(R, d, device=DEV)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    gam = torch.ones(d, device=DEV)
+
+    def ln(s):
+        dx = torch.zeros(R, d, device=DEV)
+        cast = torch.zeros(R, d, device=DEV, dtype=torch.bfloat16)
+        cs = torch.zeros(d, device=DEV)
+        ops.ln_bwd([ops.ln_problem(x, gam, None, mean, rstd, R, dy=dy, ldy=d, dx=dx, cast=cast, ldc=d, cast_colsum=cs, drop_p=0.1, drop_site=3)],
+                   d, dtype, s)
+        return [dx, cast]
+    both(ln)
+
+    def cast_embed_pack(s):
+        dst = torch.zeros(R, d, device=DEV, dtype=torch.bfloat16)
+        ops.rows_cast(dtype, [ops.cast_problem(x, d, R, d, dst_ct=dst, ldd=d, drop_p=0.1, drop_site=4)], s)
+        xe = torch.randn(10, 3, d, device=DEV)
+        oe = torch.zeros(10, 3, d, device=DEV)
+        from bpmult_amd.engine import sinusoid_table
+        ops.embed_pos_fwd([ops.embed_problem(xe, oe, 10, 3, drop_p=0.25, drop_site=6)], sinusoid_table(16, d, torch.device(DEV)), d, d ** 0.5, s)
+        src = torch.randn(3, 10, 40, device=DEV)
+        pk = torch.zeros(30, 64, device=DEV, dtype=torch.bfloat16)
+        ops.pack_rows_fwd(dtype, [ops.pack_problem(3, 10, 40, 64, src=src, dst=pk, drop_p=0.25, drop_site=7)], s)
+        return [dst, oe, pk]
+    torch.manual_seed(0)
+    a = cast_embed_pack(seed)
+    torch.manual_seed(0)
+    b = cast_embed_pack(ind)
+    for u, w in zip(a, b):
+        assert torch.equal(u, w)
+    # a new value stored in the same word changes the masks of the next launch (nothing was baked in at launch time)
+    o1 = gemm(ind)[0]
+    sd.fill_(seed + 1)
+    o2 = gemm(ind)[0]
+    assert not torch.equal(o1, o2)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_kv_layernorm_folding(dtype):
     """pack_weights(colscale) + fold_bias + unfold_grads reproduce y = LN(x; gamma, beta) W^T + b and its gradients
@@ -773,67 +854,6 @@ def test_tail_fwd_bwd_against_torch(n, B, d, Cn, Ns, pdrop):
         close(gW["Wg"][i] - 1, Wgr[i].grad, tg, f"dWg{i}")
     for nm, got, ref in zip(("dW1", "db1", "dW2", "db2", "dWo", "dbo"), gW["misc"], (W1r, b1r, W2r, b2r, Wor, bor)):
         close(got - 1, ref.grad, tg, nm)
-
-
-@pytest.mark.parametrize("B,T,S,masked,pa,pr", [(5, 50, 50, True, 0.0, 0.0), (3, 40, 64, True, 0.1, 0.1), (2, 64, 33, True, 0.0, 0.2),
-                                                  (4, 50, 50, False, 0.1, 0.0), (1, 1, 7, True, 0.0, 0.0)])
-def test_fused_crossmodal_block_matches_separate_kernels(B, T, S, masked, pa, pr):
-    """bpm_xblock_fwd (Q/K/V projections + attention + output projection + residual in one launch; hidden 768, 6 heads
-    of 128, T, S <= 64) against (a) the separate HIP kernels it replaces, same dropout sites and seed, on every tensor it
-    produces or saves for backward, and (b) fp64 torch on the bf16-rounded operands at dropout 0."""
-    H, dh, d = 6, 128, 768
-    ct = torch.bfloat16
-    g = torch.Generator().manual_seed(17)
-    rb = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(ct)
-    xq, xk, xv = rb(T * B, d), rb(S * B, d), rb(S * B, d)
-    Wq, Wk, Wv, Wo = (rb(d, d, sc=d ** -0.5) for _ in range(4))
-    bq, bk, bv, bo = (torch.randn(d, generator=g) * 0.1 for _ in range(4))
-    resid = torch.randn(T * B, d, generator=g)
-    scale = dh ** -0.5
-    off = 1 + abs(S - T) if masked else (1 << 30)
-    D = lambda t: t.to(DEV).contiguous()
-    dev = {k: D(v) for k, v in dict(xq=xq, xk=xk, xv=xv, Wq=Wq, Wk=Wk, Wv=Wv, Wo=Wo, bq=bq, bk=bk, bv=bv, bo=bo, resid=resid).items()}
-
-    def bufs():
-        return dict(qh=torch.zeros(B, H, T, dh, device=DEV, dtype=ct), kh=torch.zeros(B, H, S, dh, device=DEV, dtype=ct),
-                    vh=torch.zeros(B, H, S, dh, device=DEV, dtype=ct), ao=torch.zeros(T * B, d, device=DEV, dtype=ct),
-                    lse=torch.zeros(B, H, T, device=DEV), out=torch.full((T * B, d), float("nan"), device=DEV))
-
-    # (a) separate kernels
-    u = bufs()
-    proj = lambda x, W, b_, dst, L, alpha: ops.gemm_problem(dev[x], dev[W], dst, L * B, d, d, d, d, 0, bias_n=dev[b_], alpha=alpha,
-                                                            out_kind=OUT_HEADS, heads=(B, H, L, dh, dh), flags=ops.F_KPAD)
-    ops.gemm_grouped(BPM_BF16, GEMM_NT, [proj("xq", "Wq", "bq", u["qh"], T, scale), proj("xk", "Wk", "bk", u["kh"], S, 1.0),
-                                         proj("xv", "Wv", "bv", u["vh"], S, 1.0)], 31)
-    ops.attn_fwd(BPM_BF16, [ops.attn_problem(u["qh"], u["kh"], u["vh"], u["ao"], d, u["lse"], B, H, T, S, dh, dh, off, drop_p=pa, drop_site=9)], 31)
-    ops.gemm_grouped(BPM_BF16, GEMM_NT, [ops.gemm_problem(u["ao"], dev["Wo"], u["out"], T * B, d, d, d, d, d, bias_n=dev["bo"],
-                                                          resid=dev["resid"], ldr=d, drop_p=pr, drop_site=11, flags=ops.F_KPAD)], 31)
-    # fused
-    f = bufs()
-    p = ops.xblock_problem(dev["xq"], dev["xk"], dev["xv"], dev["Wq"], dev["bq"], dev["Wk"], dev["bk"], dev["Wv"], dev["bv"], dev["Wo"], dev["bo"],
-                           dev["resid"], f["out"], f["qh"], f["kh"], f["vh"], f["ao"], d, f["lse"], B, H, T, S, d, d, off, scale,
-                           attn_drop=pa, attn_site=9, res_drop=pr, res_site=11)
-    ops.xblock_fwd(BPM_BF16, [p, p] if B == 1 else [p], 31)
-    torch.cuda.synchronize()
-    for k in ("qh", "kh", "vh"):
-        close(f[k].float(), u[k].float().cpu(), 8e-3, k)          # one bf16 ulp of a differently ordered k sum
-    close(f["lse"], u["lse"].cpu(), 2e-2, "lse")
-    close(f["ao"].float(), u["ao"].float().cpu(), 2e-2, "ao")
-    close(f["out"], u["out"].cpu(), 3e-2, "out")
-    if pr > 0:
-        dropped = lambda t: ((t - dev["resid"]).abs() < 1e-12)
-        assert (dropped(f["out"]) == dropped(u["out"])).float().mean() > 0.999, "residual-dropout mask must be the same"
-    # (b) fp64 reference, dropout 0
-    if pa == 0 and pr == 0:
-        X = lambda t, L: t.double().reshape(L, B, d)
-        q = ((X(xq, T) @ Wq.double().T + bq.double()) * scale).to(ct).double().reshape(T, B, H, dh).permute(1, 2, 0, 3)
-        k_ = (X(xk, S) @ Wk.double().T + bk.double()).to(ct).double().reshape(S, B, H, dh).permute(1, 2, 0, 3)
-        v_ = (X(xv, S) @ Wv.double().T + bv.double()).to(ct).double().reshape(S, B, H, dh).permute(1, 2, 0, 3)
-        o_ref, lse_ref = attn_ref(q, k_, v_, off if masked else 0, torch.ones(B, H, T, S, dtype=torch.float64))
-        o_rows = o_ref.permute(2, 0, 1, 3).reshape(T * B, d)
-        out_ref = o_rows.to(ct).double() @ Wo.double().T + bo.double() + resid.double()
-        close(f["lse"], lse_ref, 2e-2, "lse vs fp64")
-        close(f["out"], out_ref, 3e-2, "out vs fp64")
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])

@@ -4,8 +4,8 @@ shape d=300 / 12 heads / 8 layers at B=2).  Inputs and weights are regenerated
 from names (tests/golden/detgen.py); the fixtures hold reference outputs only.
 
 Tolerances: f32 mode -- logits/gates 1e-4 abs on O(1) values (north-star bar is
-1e-3 relative), gradients 2e-3 relative to the tensor's max; bf16 mode --
-stated tolerance 5e-2 relative L2."""
+1e-3 relative), gradients 2e-3 relative to the tensor's max; bf16 mode -- <= 2x
+the errors measured against the same fixtures (profiles/r03_parity_errors.json)."""
 import os
 from types import SimpleNamespace
 
@@ -45,12 +45,14 @@ def err(a, b):
         float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-12))
 
 
-# Stated bf16-mode tolerances (relative L2 of the whole tensor): outputs 5e-2; per-tensor gradients 2e-1 at
-# the BASELINE shape (f9).  On the d=24 toy models a few LayerNorm-affine gradients of the level-2 encoders
-# are 1e-3-sized sums of cancelling terms and bf16 rounding noise reaches 25 % of them, so the toys use 3.5e-1
-# (their f32-mode run pins the arithmetic to 2e-3; the gradient NORM of every parameter is held to 1e-1).
-BF16_FWD, BF16_GRAD, BF16_GRAD_TOY = 5e-2, 2e-1, 3.5e-1
-BF16_GNORM_BIG = 1e-1
+# bf16-mode tolerances, held to <= 2x what profiles/r03_parity_errors.json records against the reference fixtures
+# (relative L2 of the whole tensor).  Measured: logits 0.8-1.15e-2 (F7-F11; max-abs / max-abs 1.0-1.6e-2), gates 2.7-4.5e-3,
+# loss <= 3.2e-3; worst per-tensor gradient 0.15-0.17 at the BASELINE shapes (F9, F11: a LayerNorm gain / in_proj bias
+# of a level-2 encoder, 1e-3-sized sums of cancelling terms), 0.25 on the d=24 toys; worst gradient NORM 2.3e-2 (F11),
+# 6.3e-2 (F9), 9e-2 (F10, five biprojection layers).  The f32 mode is the one held to the north star's 1e-3
+# (measured 4-6e-6 on logits); the reference itself moves 1.1e-2 under bf16 autocast (hard parts).
+BF16_FWD, BF16_GRAD, BF16_GRAD_TOY = 2.5e-2, 3e-1, 4e-1
+BF16_GNORM_BIG = 5e-2
 
 
 def check(a, b, prec, what, f32_rel=2e-3, f32_abs=None, bf16_rel=BF16_FWD):
@@ -188,7 +190,7 @@ def test_f10_cfg3_shape(prec):
 
     # bf16 mode, stated: gradient norms within 1.5e-1 here (five biprojection layers at head_dim 128: measured worst
     # 1.1e-1 on one level-2 in_proj_weight); the f32 mode holds every norm to 5e-3
-    run_model(g, model, "f10.", inputs, call, prec, BF16_GRAD=2.5e-1, BF16_GNORM=1.5e-1)
+    run_model(g, model, "f10.", inputs, call, prec, BF16_GRAD=1.5e-1, BF16_GNORM=1.5e-1)
     for k in ("xl", "img", "aud"):                      # big inputs: gradient norms only
         n = dev[k].grad.double().norm().item()
         ref = float(g["ginn." + k][0])
@@ -356,6 +358,55 @@ def test_eval_mode_no_grad_and_state_dict_round_trip():
     with torch.no_grad():
         out3 = m2(x[0], None, None, x[1], x[2])
     assert float((out3 - ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_graph_replay_equals_eager_launches(prec):
+    """The step captured into hipGraphs (forward graph + backward graph per key, dropout seed read from device memory at
+    execution time) gives bit-for-bit the logits, gates and gradients of the eager launch sequence: same dropout masks
+    (README rates on), fresh and accumulating micro-steps, a second input shape (its own key), eval mode."""
+    import copy
+    drop = dict(attn_dropout=0.1, relu_dropout=0.1, res_dropout=0.1, embed_dropout=0.25, out_dropout=0.1)
+    m1 = _toy(**drop)
+    m1.precision = prec
+    m2 = copy.deepcopy(m1)
+    m1, m2 = m1.cuda().train(), m2.cuda().train()
+    m1.use_graphs, m2.use_graphs = False, True
+    tgt = (torch.randn(2, 6, generator=torch.Generator().manual_seed(1)) > 0).float().cuda()
+    lossf = torch.nn.functional.binary_cross_entropy_with_logits
+    xa, xb = _toy_inputs(seed=4), _toy_inputs(seed=5)
+    xb[1] = xb[1][:, :40].contiguous()                          # another video length: another graph key
+    plan = [(xa, True), (xa, True), (xa, True), (xa, False), (xb, True), (xb, True), (xb, True), (xa, True), (xb, False)]
+    for step, (x, clear) in enumerate(plan):
+        outs = []
+        for m in (m1, m2):
+            if clear:
+                for p in m.parameters():
+                    p.grad = None
+            xs = [t.clone().requires_grad_(True) for t in x]
+            logits, z = m(xs[0], None, None, xs[1], xs[2], output_gate=True)
+            lossf(logits, tgt).backward()
+            outs.append((logits.detach().clone(), z.detach().clone(), [t.grad.clone() for t in xs],
+                         {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+        a, b = outs
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), f"step {step}: logits / gates differ"
+        for u, v in zip(a[2], b[2]):
+            assert torch.equal(u, v), f"step {step}: input gradients differ"
+        assert a[3].keys() == b[3].keys()
+        for k in a[3]:
+            if "gmu." in k or k.startswith(("proj1", "proj2", "out_layer")) or "layer_norm" in k or "bias" in k:
+                # float atomics / two-stream arrival order in the tail and the column sums: same values up to rounding
+                assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-5 * max(1.0, float(a[3][k].abs().max())), (step, k)
+            else:
+                assert torch.equal(a[3][k], b[3][k]), f"step {step}: gradient of {k} differs"
+    t2 = m2._trunks[2]
+    assert len(t2._fg) >= 2 and sum("graph" in e for e in t2._fg.values()) >= 2, "both input shapes were captured"
+    assert any("graph" in e for e in t2._bg.values())
+    assert getattr(m1._trunks[2], "_fg", None) in (None, {})
+    m1.eval(), m2.eval()
+    with torch.no_grad():
+        for _ in range(4):
+            assert torch.equal(m1(xa[0], None, None, xa[1], xa[2]), m2(xa[0], None, None, xa[1], xa[2]))
 
 
 def test_master_level_writes_refresh_the_weight_shadows():

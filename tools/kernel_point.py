@@ -1,13 +1,22 @@
 #!/usr/bin/env python3
 """The north-star kernel point (BASELINE.json: "fused biprojection crossmodal-attention kernel at hidden_sz=768 /
 seq_len=50"): one crossmodal attention block -- Q / K / V projections, masked softmax attention, output projection with
-residual -- for six lock-stepped encoders at d=768, H=6 (head_dim 128), T=S=50, B=64, bf16, README dropout rates.
+residual -- for six lock-stepped encoders at d=768, H=6 (head_dim 128), T=S=50, B=64, bf16, README dropout rates,
+forward and backward, through the launches the product path uses (engine.EncoderGroupPlan):
+
+  forward : one grouped GEMM for the 18 Q / K / V projections (head-major outputs), attention, one grouped GEMM for the
+            six output projections (+ bias, dropout, fp32 residual)
+  backward: d(out) . Wo (head-major), attention dQ + dK/dV, the three data-gradient GEMMs (d(xn), d(khat), d(vhat)) and
+            one grouped weight-gradient GEMM of 24 problems (q, k, v, out; bias sums ride on it)
 
   python tools/kernel_point.py            (MI355X only; also imported by bench.py for its `kernel_point` object)
 
-Timed stand-alone with HIP events (median of --iters launches, random data): the fused launch (bpm_xblock_fwd) and the
-five separate launches it replaces (grouped Q/K/V projection GEMM, attention, output projection GEMM).  Algorithmic
-FLOPs per sample and layer = (4T + 4S) d^2 + 4 P(T,S) d (P = visible (query, key) pairs)."""
+Timed stand-alone with HIP events (median of --iters, random data).  Algorithmic FLOPs per sample and layer, forward =
+(4T + 4S) d^2 + 4 P(T,S) d (P = visible (query, key) pairs); backward = 2x.  A single fused launch
+(one 64-row workgroup per encoder and batch element) was built in round 2 and measured at 7.6 % of the MFMA peak against
+19 % for these launches; it was removed in round 3 (DESIGN.md section 5 has the analysis: at 50-row sequences a fused
+workgroup streams every 768 x 768 weight through its own LDS for 64-128 rows, which is bound by LDS-DMA issue, while
+the grouped GEMMs amortise the same bytes over 3200-row problems)."""
 import argparse
 import json
 import os
@@ -40,61 +49,81 @@ def _time(fn, iters):
 def measure(dev="cuda", d=768, H=6, T=50, S=50, B=64, G=6, iters=20):
     import bpmult_amd  # noqa: F401
     from bpmult_amd import ops
-    from bpmult_amd.ops import BPM_BF16, F_KPAD, GEMM_NT, OUT_HEADS
+    from bpmult_amd.ops import BPM_BF16, F_ACCUM, F_KPAD, GEMM_NN, GEMM_NT, GEMM_TN, OUT_HEADS
 
     dh, ct = d // H, torch.bfloat16
     g = torch.Generator().manual_seed(5)
     rb = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(ct).to(dev)
     rf = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    zb = lambda *s: torch.zeros(*s, device=dev, dtype=ct)
+    zf = lambda *s: torch.zeros(*s, device=dev)
     off, scale = 1 + abs(S - T), dh ** -0.5
-    keep, fused, qkv, att, outp = [], [], [], [], []
+    keep, qkv, att, outp = [], [], [], []
+    dgo, batt, dgq, dgkv, wg = [], [], [], [], []
+    Rq, Rk = T * B, S * B
     for e in range(G):
-        t = dict(xq=rb(T * B, d), xk=rb(S * B, d), xv=rb(S * B, d), Wq=rb(d, d, sc=d ** -0.5), Wk=rb(d, d, sc=d ** -0.5),
+        t = dict(xq=rb(Rq, d), xk=rb(Rk, d), xv=rb(Rk, d), Wq=rb(d, d, sc=d ** -0.5), Wk=rb(d, d, sc=d ** -0.5),
                  Wv=rb(d, d, sc=d ** -0.5), Wo=rb(d, d, sc=d ** -0.5), bq=rf(d, sc=0.1), bk=rf(d, sc=0.1), bv=rf(d, sc=0.1), bo=rf(d, sc=0.1),
-                 resid=rf(T * B, d), out=torch.zeros(T * B, d, device=dev), qh=torch.zeros(B, H, T, dh, device=dev, dtype=ct),
-                 kh=torch.zeros(B, H, S, dh, device=dev, dtype=ct), vh=torch.zeros(B, H, S, dh, device=dev, dtype=ct),
-                 ao=torch.zeros(T * B, d, device=dev, dtype=ct), lse=torch.zeros(B, H, T, device=dev))
+                 resid=rf(Rq, d), out=zf(Rq, d), qh=zb(B, H, T, dh), kh=zb(B, H, S, dh), vh=zb(B, H, S, dh), ao=zb(Rq, d), lse=zf(B, H, T),
+                 dy=rb(Rq, d), dao=zb(B, H, T, dh), delta=zf(B, H, T), dq=zb(Rq, d), dk=zb(Rk, d), dv=zb(Rk, d), dxn=zf(Rq, d),
+                 Gk=zf(Rk, d), Gv=zf(Rk, d), gWq=zf(d, d), gWk=zf(d, d), gWv=zf(d, d), gWo=zf(d, d), gb=zf(3 * d))
         keep.append(t)
-        fused.append(ops.xblock_problem(t["xq"], t["xk"], t["xv"], t["Wq"], t["bq"], t["Wk"], t["bk"], t["Wv"], t["bv"], t["Wo"], t["bo"],
-                                        t["resid"], t["out"], t["qh"], t["kh"], t["vh"], t["ao"], d, t["lse"], B, H, T, S, d, d, off, scale,
-                                        attn_drop=0.1, attn_site=9 + 16 * e, res_drop=0.1, res_site=11 + 16 * e))
         for x, W, b_, dst, L, al in (("xq", "Wq", "bq", "qh", T, scale), ("xk", "Wk", "bk", "kh", S, 1.0), ("xv", "Wv", "bv", "vh", S, 1.0)):
             qkv.append(ops.gemm_problem(t[x], t[W], t[dst], L * B, d, d, d, d, 0, bias_n=t[b_], alpha=al, out_kind=OUT_HEADS,
                                         heads=(B, H, L, dh, dh), flags=F_KPAD))
-        att.append(ops.attn_problem(t["qh"], t["kh"], t["vh"], t["ao"], d, t["lse"], B, H, T, S, dh, dh, off, drop_p=0.1, drop_site=9 + 16 * e))
-        outp.append(ops.gemm_problem(t["ao"], t["Wo"], t["out"], T * B, d, d, d, d, d, bias_n=t["bo"], resid=t["resid"], ldr=d,
+        ap = ops.attn_problem(t["qh"], t["kh"], t["vh"], t["ao"], d, t["lse"], B, H, T, S, dh, dh, off, dO=t["dao"], delta=t["delta"],
+                              dQ=t["dq"], lddq=d, dK=t["dk"], lddk=d, dV=t["dv"], lddv=d, dq_scale=scale, drop_p=0.1, drop_site=9 + 16 * e)
+        att.append(ap)
+        outp.append(ops.gemm_problem(t["ao"], t["Wo"], t["out"], Rq, d, d, d, d, d, bias_n=t["bo"], resid=t["resid"], ldr=d,
                                      drop_p=0.1, drop_site=11 + 16 * e, flags=F_KPAD))
-    fa, qa, aa, oa = (ops.array(c, p) for c, p in ((ops._lib.XBlockProblem, fused), (ops.GemmProblem, qkv), (ops.AttnProblem, att),
-                                                   (ops.GemmProblem, outp)))
+        dgo.append(ops.gemm_problem(t["dy"], t["Wo"], t["dao"], Rq, d, d, d, d, 0, out_kind=OUT_HEADS, heads=(B, H, T, dh, dh), flags=F_KPAD))
+        dgq.append(ops.gemm_problem(t["dq"], t["Wq"], t["dxn"], Rq, d, d, d, d, d, flags=F_KPAD))
+        dgkv.append(ops.gemm_problem(t["dk"], t["Wk"], t["Gk"], Rk, d, d, d, d, d, flags=F_KPAD | F_ACCUM))
+        dgkv.append(ops.gemm_problem(t["dv"], t["Wv"], t["Gv"], Rk, d, d, d, d, d, flags=F_KPAD | F_ACCUM))
+        wg.append(ops.gemm_problem(t["dy"], t["ao"], t["gWo"], d, d, Rq, d, d, d, flags=F_KPAD | F_ACCUM))
+        for gsrc, x, gw, j, R in (("dq", "xq", "gWq", 0, Rq), ("dk", "xk", "gWk", 1, Rk), ("dv", "xv", "gWv", 2, Rk)):
+            wg.append(ops.gemm_problem(t[gsrc], t[x], t[gw], d, d, R, d, d, d, flags=F_KPAD | F_ACCUM, colsum_a=t["gb"][j * d:(j + 1) * d]))
+    A = ops.array
+    qa, aa, oa = A(ops.GemmProblem, qkv), A(ops.AttnProblem, att), A(ops.GemmProblem, outp)
+    ga, gq, gkv, gw = A(ops.GemmProblem, dgo), A(ops.GemmProblem, dgq), A(ops.GemmProblem, dgkv), A(ops.GemmProblem, wg)
 
-    def separate():
+    def forward():
         ops.gemm_grouped(BPM_BF16, GEMM_NT, qa, 3)
         ops.attn_fwd(BPM_BF16, aa, 3)
         ops.gemm_grouped(BPM_BF16, GEMM_NT, oa, 3)
 
-    us_f = _time(lambda: ops.xblock_fwd(BPM_BF16, fa, 3), iters)
-    us_s = _time(separate, iters)
+    def backward():
+        ops.gemm_grouped(BPM_BF16, GEMM_NN, ga, 3)
+        ops.attn_bwd(BPM_BF16, aa, 3)
+        ops.gemm_grouped(BPM_BF16, GEMM_NN, gq, 3)
+        ops.gemm_grouped(BPM_BF16, GEMM_NN, gkv, 3)
+        ops.gemm_grouped(BPM_BF16, GEMM_TN, gw, 3)
+
+    parts = {"qkv_proj": lambda: ops.gemm_grouped(BPM_BF16, GEMM_NT, qa, 3), "attn_fwd": lambda: ops.attn_fwd(BPM_BF16, aa, 3),
+             "out_proj": lambda: ops.gemm_grouped(BPM_BF16, GEMM_NT, oa, 3), "d_out": lambda: ops.gemm_grouped(BPM_BF16, GEMM_NN, ga, 3),
+             "attn_bwd": lambda: ops.attn_bwd(BPM_BF16, aa, 3), "d_q": lambda: ops.gemm_grouped(BPM_BF16, GEMM_NN, gq, 3),
+             "d_kv": lambda: ops.gemm_grouped(BPM_BF16, GEMM_NN, gkv, 3), "wgrad": lambda: ops.gemm_grouped(BPM_BF16, GEMM_TN, gw, 3)}
+    us_f = _time(forward, iters)
+    us_b = _time(backward, iters)
+    us_parts = {k: round(_time(fn, iters), 1) for k, fn in parts.items()}
     pairs = sum(min(S, t + off) for t in range(T))
     flops_sample = (4 * T + 4 * S) * d * d + 4 * pairs * d
     flops = flops_sample * B * G
-    # algorithmic HBM bytes of the fused launch: bf16 sources in, fp32 residual in / out, bf16 weights once per encoder,
+    # algorithmic HBM bytes of the forward block: bf16 sources in, fp32 residual in / out, bf16 weights once per encoder,
     # tensors saved for backward (q / k / v heads, attention output, LSE)
     hbm = G * (B * (T + 2 * S) * d * 2 + 2 * B * T * d * 4 + 4 * d * d * 2 + B * (T + 2 * S) * d * 2 + B * T * d * 2 + B * H * T * 4)
-    tf = flops / us_f / 1e6
-    return {"what": "forward crossmodal-attention block (Q/K/V projections + masked softmax attention + output projection + residual), "
-                    "six encoders per launch, bf16, dropout .1/.1, stand-alone",
+    tf, tfb = flops / us_f / 1e6, 3 * flops / (us_f + us_b) / 1e6
+    return {"what": "crossmodal-attention block (Q/K/V projections + masked softmax attention + output projection + residual), six "
+                    "encoders per launch, bf16, dropout .1/.1, stand-alone, through the product path's launches",
             "shape": {"d": d, "H": H, "head_dim": dh, "T": T, "S": S, "B": B, "encoders": G},
-            "fused_us": round(us_f, 1), "separate_kernels_us": round(us_s, 1), "launches_replaced": 5,
+            "forward_us": round(us_f, 1), "backward_us": round(us_b, 1), "launches": {"forward": 3, "backward": 6}, "launch_us": us_parts,
             "flops_per_sample_layer": flops_sample, "flops_per_launch": flops, "tflops": round(tf, 1), "peak_tflops": PEAK,
-            "frac": round(tf / PEAK, 4), "target_frac": 0.30,
+            "frac": round(tf / PEAK, 4), "tflops_fwd_bwd": round(tfb, 1), "frac_fwd_bwd": round(tfb / PEAK, 4), "target_frac": 0.30,
             "algorithmic_hbm_bytes": hbm, "flop_per_byte": round(flops / hbm, 1),
-            "tflops_separate": round(flops / us_s / 1e6, 1), "frac_separate": round(flops / us_s / 1e6 / PEAK, 4),
-            "product_path": "separate kernels (engine.FUSE_SHORT_BLOCKS = False): the fused launch is correct but slower",
-            "why_short_of_target": "98 % of the block's flops are four 768 x 768 projections per 50-row sequence; one 64-row workgroup per "
-                                   "(encoder, batch element) needs 6 LDS-DMA instructions per 16 MFMAs and is paced by their issue cost "
-                                   "(~150 cycles each), and 384 workgroups of 144 KB LDS run in two rounds on 256 CUs; the grouped GEMMs "
-                                   "amortise the same weight bytes over 3200-row problems but stop at ~500 TFLOP/s for K = N = 768 "
-                                   "(main loop and fp32 epilogue do not overlap: DESIGN.md section 5)"}
+            "why_short_of_target": "98 % of the block's flops are four 768 x 768 projections per 50-row sequence: K = N = 768 products of "
+                                   "3200 rows, whose 12-stage main loops (about 50 % of the MFMA rate while they run) sit between a "
+                                   "pipeline fill and an epilogue of similar length; a fused per-sequence workgroup (removed in round 3) "
+                                   "was 2.5x slower still (DESIGN.md section 5)"}
 
 
 if __name__ == "__main__":
