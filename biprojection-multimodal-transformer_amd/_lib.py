@@ -146,6 +146,10 @@ class GmuProblem(C.Structure):
                 ("ldg", C.c_int), ("dx1", C.c_void_p), ("dx2", C.c_void_p), ("R", C.c_int)]
 
 
+class AddnProblem(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("src", C.c_void_p * 8), ("n_in", C.c_int), ("count", C.c_size_t)]
+
+
 class TailDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("d", C.c_int), ("n", C.c_int), ("C", C.c_int), ("N", C.c_int * 3),
                 ("top", C.c_void_p * 3), ("mid", C.c_void_p * 3), ("extra", C.c_void_p),
@@ -186,6 +190,7 @@ SIGNATURES = {
     "bpm_ln_bwd_ws": [_I, C.POINTER(LnProblem), _I, _I, _U64, _P, C.c_size_t, _P],
     "bpm_ln_bwd_ws_bytes": [_I, _I],
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
+    "bpm_add_n": [C.POINTER(AddnProblem), _I, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_im2col1d": [_I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _P],

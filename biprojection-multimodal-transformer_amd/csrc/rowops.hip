@@ -733,6 +733,31 @@ __global__ void gmu2_bwd_kernel(const Grp<GmuP> grp, int d) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// out = sum_j in[j] over `count` fp32 elements (count % 4 == 0, 16-byte aligned; out may be one of the inputs).
+// The sums of gradient contributions that meet at a tensor several consumers read: a level-1 output feeds a Fusion-GMU
+// twice and a level-2 encoder as key and value source; a projected input feeds up to eight encoders.
+// ---------------------------------------------------------------------------
+struct AddP { float* out; const float* in[BPM_ADDN_MAX]; int n_in; unsigned count4, tail; };
+
+__global__ __launch_bounds__(NT) void add_n_kernel(const Grp<AddP> grp) {
+    unsigned bid = blockIdx.x, nblk;
+    const AddP& P = pick(grp, bid, nblk);
+    for (unsigned q = bid * NT + threadIdx.x; q < P.count4; q += nblk * NT) {
+        f32x4 acc = *(const f32x4*)(P.in[0] + 4 * (size_t)q);
+#pragma unroll
+        for (int j = 1; j < BPM_ADDN_MAX; ++j)
+            if (j < P.n_in) acc += *(const f32x4*)(P.in[j] + 4 * (size_t)q);
+        *(f32x4*)(P.out + 4 * (size_t)q) = acc;
+    }
+    if (bid == 0 && threadIdx.x < P.tail) {            // count % 4 trailing elements
+        const size_t i = 4 * (size_t)P.count4 + threadIdx.x;
+        float a = P.in[0][i];
+        for (int j = 1; j < P.n_in; ++j) a += P.in[j][i];
+        P.out[i] = a;
+    }
+}
+
 constexpr unsigned CAP = 2048;   // blocks per problem for grid-stride kernels
 
 template <typename P> inline bool grp_ok(int n) { return n >= 1 && n <= BPM_MAX_GROUP; }
@@ -1078,6 +1103,29 @@ extern "C" int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* q, int n, int d, v
     int rc = fill_gmu(g, q, n, d, true);
     if (rc) return rc;
     BPM_DISPATCH_CT(dtype, gmu2_bwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, d);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bpm_add_n(const bpm_addn_problem* q, int n, void* stream) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
+    Grp<AddP> g;
+    g.n = n; g.blk0[0] = 0; g.seedp = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const bpm_addn_problem& s = q[i];
+        if (!s.out || s.n_in < 1 || s.n_in > BPM_ADDN_MAX || s.count < 1 || s.count > (size_t)1 << 33) return BPM_ERR_ARG;
+        AddP& p = g.p[i];
+        uintptr_t al = (uintptr_t)s.out;
+        for (int j = 0; j < BPM_ADDN_MAX; ++j) {
+            p.in[j] = j < s.n_in ? s.src[j] : s.src[0];
+            if (j < s.n_in && !s.src[j]) return BPM_ERR_ARG;
+            al |= (uintptr_t)p.in[j];
+        }
+        if (al & 15) return BPM_ERR_ALIGN;
+        p.out = s.out; p.n_in = s.n_in; p.count4 = (unsigned)(s.count >> 2); p.tail = (unsigned)(s.count & 3);
+        g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)p.count4, NT * 4, CAP);
+    }
+    hipLaunchKernelGGL(add_n_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
     BPM_CHECK_LAUNCH();
     return 0;
 }

@@ -194,10 +194,11 @@ class ParamStore:
     # -- shadows --------------------------------------------------------------
     def add_shadow(self, key: str, name: str, rows: int, cols: int, *, src_col0: int = 0, src_ld: Optional[int] = None,
                    dst_ld: Optional[int] = None, dst_col0: int = 0, base_key: Optional[str] = None, src_row0: int = 0,
-                   colscale: Optional[str] = None) -> None:
+                   colscale: Optional[str] = None, dst_row0: int = 0) -> None:
         """Register a CT shadow [rows, dst_ld] of master `name` viewed as [.., src_ld][src_row0:src_row0+rows,
-        src_col0:src_col0+cols].  base_key: write into an already registered shadow (column block dst_col0) instead
-        of a new one.  colscale: name of a [cols] parameter multiplied into the columns (LayerNorm gain folding)."""
+        src_col0:src_col0+cols].  base_key: write into an already registered shadow (block at row dst_row0, column
+        dst_col0) instead of a new one.  colscale: name of a [cols] parameter multiplied into the columns (LayerNorm gain
+        folding)."""
         ld = pad32(cols)
         src_ld = cols if src_ld is None else src_ld
         dst_ld = ld if dst_ld is None else dst_ld
@@ -206,9 +207,14 @@ class ParamStore:
             off = self._shadow_total
             self._shadow_total += rows * dst_ld
         else:
-            off = self._shadow_off[base_key]
+            off = self._shadow_off[base_key] + dst_row0 * dst_ld
             self._shadow_off[key] = off + dst_col0
         self._shadow_specs.append((name, rows, cols, ld, src_ld, dst_ld, src_col0 + src_row0 * src_ld, off + dst_col0, colscale))
+
+    def add_blank_shadow(self, key: str, rows: int, ld: int) -> None:
+        """Reserve a zero-filled CT region [rows, ld] that later add_shadow(base_key=key, ...) calls fill block by block."""
+        self._shadow_off[key] = self._shadow_total
+        self._shadow_total += rows * ld
 
     def add_fold(self, key: str, wname: str, row0: int, rows: int, cols: int, beta: str, bias: str, bias_off: int) -> None:
         """Register a folded bias out[rows] = bias[bias_off:] + W[row0:row0+rows, :cols] . beta (fp32)."""
@@ -369,7 +375,7 @@ class EncoderGroupPlan:
         L = cfg.layers
         self.buf: List[dict] = []
         # accumulators that every backward starts from zero (d(khat), d(vhat), folded bias sums): ONE buffer, one fill
-        nacc = sum(2 * (e.S * B * d + 16) + L * 2 * d + 16 for e in self.encs)
+        nacc = sum(L * 2 * d + 16 for e in self.encs)
         self._acc0 = torch.zeros(nacc, device=dev, dtype=torch.float32)
         acc_off = [0]
 
@@ -392,7 +398,11 @@ class EncoderGroupPlan:
             # into the K / V projection weights, see register_encoder_shadows)
             b["khat"], b["vhat"] = z(Rk, self.ld, dt=ct), z(Rk, self.ld, dt=ct)
             b["stk"], b["stv"] = (z(Rk), z(Rk)), (z(Rk), z(Rk))
-            b["Gk"], b["Gv"] = carve(Rk, d), carve(Rk, d)           # sum over layers of d(khat), d(vhat)
+            # d(khat), d(vhat) = sum over the layers of dK_i Wk'_i, dV_i Wv'_i: ONE product over K = L ld per encoder at the
+            # end of backward (dK_i / dV_i of every layer are kept side by side in dkall / dvall) instead of L products
+            # accumulating into the same fp32 [Rk, d] tensor (8 x 300 MB of read-modify-write per level at hidden 768)
+            b["Gk"], b["Gv"] = z(Rk, d), z(Rk, d)
+            b["dkall"], b["dvall"] = z(Rk, L * self.ld, dt=ct), z(Rk, L * self.ld, dt=ct)
             b["dWf"] = [z(2 * d, d) for _ in range(L)]              # folded K/V weight gradients (per backward)
             b["dbf"] = carve(L, 2 * d)                              # folded K/V bias gradients (column sums)
             for nm, shape, dt in (("xn", (R, self.ld), ct),
@@ -418,7 +428,7 @@ class EncoderGroupPlan:
             b["dy"], b["dh1"] = two(R, self.ld), two(R, self.ld4)
             # dyf[i % 3]: written one layer early (fused into the LayerNorm backward that produces dx)
             b["dyf"] = [z(R, self.ld, dt=ct) for _ in range(3)]
-            b["dq"], b["dk"], b["dv"] = two(R, self.ld), two(Rk, self.ld), two(Rk, self.ld)
+            b["dq"] = two(R, self.ld)
             if cfg.biprojection:
                 b["dy0"] = two(R, self.ld)
                 # dQ | dK | dV of the self-attention half side by side in one [R, 3 ld] buffer: without column padding
@@ -510,7 +520,7 @@ class EncoderGroupPlan:
 
                 def proj_kv(Ain, which, Cout):       # folded: khat (W_k * gamma)^T + (W_k beta + b_k)
                     kvf = self._pn(e, i, KVF)
-                    return ops.gemm_problem(Ain, st.sptr(kvf, (which - 1) * d * ld), Cout, Rk, d, d, ld, ld, 0,
+                    return ops.gemm_problem(Ain, st.sptr(kvf + (".k" if which == 1 else ".v")), Cout, Rk, d, d, ld, ld, 0,
                                             bias_n=st.fold(kvf, (which - 1) * d, d), out_kind=OUT_HEADS,
                                             heads=(B, H, e.S, dh, dhp))
 
@@ -682,7 +692,7 @@ class EncoderGroupPlan:
         inv_relu = 1.0 / (1.0 - pr(c.relu_dropout))
         for i in reversed(range(c.layers)):
             wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], []
-            wg_att, dg_out, att, dg_q, dg_kv, lnq = [], [], [], [], [], []
+            wg_att, dg_out, att, dg_q, lnq = [], [], [], [], []
             s_cast0, s_dgout0, s_att0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], []
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -695,7 +705,9 @@ class EncoderGroupPlan:
                 stF = (b["st2m"][i], b["st2r"][i]) if c.biprojection else (b["st1m"][i], b["st1r"][i])
                 dx = b["dx"]
                 par = i & 1
-                dh1, dy, dq, dk, dv, dao, delta = (b[n][par] for n in ("dh1", "dy", "dq", "dk", "dv", "dao", "delta"))
+                dh1, dy, dq, dao, delta = (b[n][par] for n in ("dh1", "dy", "dq", "dao", "delta"))
+                ldk = c.layers * ld                       # layer i's dK / dV: column block i of dkall / dvall
+                dk, dv = b["dkall"][:, i * ld:(i + 1) * ld], b["dvall"][:, i * ld:(i + 1) * ld]
                 dyf = b["dyf"][i % 3]
                 # hand-off to the next layer down (i-1): its FFN-output gradient dyf = dropmask(dx) and fc2.bias
                 # gradient are produced by whichever LayerNorm backward finishes this layer's dx
@@ -722,7 +734,7 @@ class EncoderGroupPlan:
                                                heads=(B, H, e.T, dh, dhp)))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
                                             self._mask_off(e.T_full or e.T, e.S), dO=dao, delta=delta, dQ=dq, lddq=ld,
-                                            dK=dk, lddk=ld, dV=dv, lddv=ld, dq_scale=self.scale,
+                                            dK=dk, lddk=ldk, dV=dv, lddv=ldk, dq_scale=self.scale,
                                             drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN),
                                             q_pos0=e.q_pos0, q_stride=e.q_stride))
                 ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
@@ -733,8 +745,8 @@ class EncoderGroupPlan:
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
                 wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, R, ld, ld, d, flags=F_ACCUM,
                                                colsum_a=st.gptr(ipb_g, 0)))
-                wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ld, ld, d, colsum_a=b["dbf"][i][:d]))
-                wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ld, ld, d, colsum_a=b["dbf"][i][d:]))
+                wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][:d]))
+                wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][d:]))
                 if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
                     dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
                 else:
@@ -742,9 +754,6 @@ class EncoderGroupPlan:
                     lnq.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R, dy=b["dxn"],
                                               ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias"),
                                               **nxt))
-                kvf = self._pn(e, i, KVF)
-                dg_kv.append(ops.gemm_problem(dk, st.sptr(kvf, 0), b["Gk"], Rk, d, d, ld, ld, d, flags=F_ACCUM))
-                dg_kv.append(ops.gemm_problem(dv, st.sptr(kvf, d * ld), b["Gv"], Rk, d, d, ld, ld, d, flags=F_ACCUM))
                 if c.biprojection:
                     # ---- self-attention half (same attention parameters)
                     s_cast0.append(ops.cast_problem(dx, d, R, d, dst_ct=dy0, ldd=ld, colsum=GP("self_attn.out_proj.bias"),
@@ -790,7 +799,6 @@ class EncoderGroupPlan:
                       ((SIDE if self._dkv_side == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
                        if self._dkv_side in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
                       (SIDE, self._gemm(GEMM_TN, wg_att, background=True)),
-                      (SIDE, self._gemm(GEMM_NN, dg_kv)),
                       self._gemm(GEMM_NN, dg_q)]
             if lnq:
                 steps.append((ops.ln_bwd, A(LnProblem, lnq), d))
@@ -805,12 +813,15 @@ class EncoderGroupPlan:
             # folded K/V gradients of this layer -> in_proj / LayerNorm parameter gradients; with it every gradient of
             # layer i is final once the side stream reaches MARK i and the main stream this point (all-reduce hook)
             steps += [(SIDE, (ops.unfold_grads,) + self._unfold[i]), (MARK, i)]
-        # d(khat), d(vhat) summed over the layers -> d(embedded key / value source): LayerNorm backward without affine
-        hat = []
+        # d(khat), d(vhat): all layers' dK / dV against the stacked projection weights, one product over K = L ld per
+        # encoder; then -> d(embedded key / value source): LayerNorm backward without affine
+        hat, dg_kv = [], []
         for e, b in zip(self.encs, self.buf):
+            dg_kv += [ops.gemm_problem(b["dkall"], st.sptr(e.prefix + KSTACK), b["Gk"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d),
+                      ops.gemm_problem(b["dvall"], st.sptr(e.prefix + VSTACK), b["Gv"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d)]
             hat += [ops.ln_problem(b["ke"], self._ones, None, b["stk"][0], b["stk"][1], b["Rk"], dy=b["Gk"], ldy=d, dx=b["dke"]),
                     ops.ln_problem(b["ve"], self._ones, None, b["stv"][0], b["stv"][1], b["Rk"], dy=b["Gv"], ldy=d, dx=b["dve"])]
-        steps += [(SIDE, (ops.ln_bwd, A(LnProblem, hat), d)), JOIN]
+        steps += [(SIDE, self._gemm(GEMM_NN, dg_kv)), (SIDE, (ops.ln_bwd, A(LnProblem, hat), d)), JOIN]
         return steps
 
     def backward(self, douts: Sequence[Optional[torch.Tensor]], on_layer=None):
@@ -852,13 +863,25 @@ class EncoderGroupPlan:
 KVF = "self_attn.in_proj_weight#kvf"      # key suffix of the folded key/value shadow and bias
 
 
+KSTACK, VSTACK = "#kstack", "#vstack"     # per-encoder stacks of the folded key / value projection weights
+
+
 def register_encoder_shadows(store: ParamStore, prefix: str, d: int, layers: int, biprojection: bool = False) -> None:
     lnK = 1 if biprojection else 0        # LayerNorm applied to the key / value source (transformer.py:167-172)
+    ld = pad32(d)
     for i in range(layers):
         p = f"{prefix}layers.{i}."
         store.add_shadow(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_weight", 3 * d, d)
-        # key / value projections with that LayerNorm folded in: W' = W * gamma (columns), b' = W beta + b
-        store.add_shadow(p + KVF, p + "self_attn.in_proj_weight", 2 * d, d, src_row0=d, colscale=p + f"layer_norms.{lnK}.weight")
+        # key / value projections with that LayerNorm folded in: W' = W * gamma (columns), b' = W beta + b.  The layers' W'
+        # are STACKED per encoder (block i = rows [i ld, i ld + d) of a [layers ld, ld] shadow, pad rows zero): layer i's
+        # projection reads its block, and the key / value-side data gradient of ALL layers is one product over K = layers ld
+        if i == 0:
+            store.add_blank_shadow(prefix + KSTACK, layers * ld, ld)
+            store.add_blank_shadow(prefix + VSTACK, layers * ld, ld)
+        store.add_shadow(p + KVF + ".k", p + "self_attn.in_proj_weight", d, d, src_row0=d, colscale=p + f"layer_norms.{lnK}.weight",
+                         base_key=prefix + KSTACK, dst_row0=i * ld)
+        store.add_shadow(p + KVF + ".v", p + "self_attn.in_proj_weight", d, d, src_row0=2 * d, colscale=p + f"layer_norms.{lnK}.weight",
+                         base_key=prefix + VSTACK, dst_row0=i * ld)
         store.add_fold(p + KVF, p + "self_attn.in_proj_weight", d, 2 * d, d, p + f"layer_norms.{lnK}.bias",
                        p + "self_attn.in_proj_bias", d)
         store.add_shadow(p + "self_attn.out_proj.weight", p + "self_attn.out_proj.weight", d, d)

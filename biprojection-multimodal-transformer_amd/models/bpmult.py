@@ -151,6 +151,7 @@ class _Trunk:
         self.plan2 = EncoderGroupPlan(st, cfg2, e2, B)
         self.out1 = {n: b["out"] for n, b in zip(LEVEL1, self.plan1.buf)}
         self.out2 = {n: b["out"] for n, b in zip(LEVEL2, self.plan2.buf)}
+        self.d1buf = {n: z(self.N[q], B, d) for n, (q, _, _) in LEVEL1.items()} if not self.prune else {}   # d(level-1 outputs)
         if self.prune:                      # rows 0 and N-1 of every level-1 output, as the GMUs see them
             self.out1g = {n: z(2, B, d) for n in LEVEL1}
         # ---- time-axis maps (4-modal only)
@@ -175,6 +176,7 @@ class _Trunk:
                                            da2=z(R, self.ld, dt=ct), dag=z(R, self.ld, dt=ct), dx1=z(R, d), dx2=z(R, d))
         self._build_gmu()
         self._conv_cache = {}
+        self._px_rows: Dict[str, int] = {k: 0 for k in self.N}     # rows of px[k] written by the previous input
         # ---- [B,d] tail (token pick, final n-way GMU, residual head): activations kept for its backward + scratch
         n = 4 if model.four_modal else 3
         Cn = model.out_layer.out_features
@@ -195,8 +197,13 @@ class _Trunk:
                 raise ValueError(f"modality {k}: sequence length {T} exceeds num_vectors_{k}={self.N[k]}")
             p = m.embed_dropout if (training and k == "l") else 0.0           # text-feature dropout, mmtr.py:741
             px = self.px[k]
-            if T < self.N[k]:
-                px[T:].zero_()
+            # rows [T, last) hold an earlier, longer input: clear them (rows past every input so far are still the zeros
+            # they were allocated as).  While capturing a graph: always the whole tail -- a replay must leave px right
+            # whatever ran before it
+            last = self.N[k] if getattr(self, "_capturing", False) else self._px_rows.get(k, self.N[k])
+            if T < last:
+                px[T:last].zero_()
+            self._px_rows[k] = T
             if od == d:                                                        # projection skipped (mmtr.py:748-750)
                 packs_f32.append(ops.pack_problem(B, T, od, d, src=x, dst=px, drop_p=p, drop_site=SITE_TEXT))
                 self._conv[k] = dict(T=T, od=od, x=x, p=p, packed=None)
@@ -403,7 +410,11 @@ class _Trunk:
         gr = TailGrads()
         gr.dlogits = dlogits.data_ptr()
         gr.dz = dz.data_ptr() if dz is not None else None
-        grads = [torch.zeros_like(p) for p in params]        # accumulated into (+=) by the kernels
+        flat = torch.zeros(sum((p.numel() + 3) // 4 * 4 for p in params), device=dlogits.device)    # accumulated into (+=) by the kernels
+        grads, o = [], 0
+        for p in params:
+            grads.append(flat[o:o + p.numel()].view(p.shape))
+            o += (p.numel() + 3) // 4 * 4
         it = iter(grads)
         for i in range(n):
             gr.dWh[i] = next(it).data_ptr()
@@ -436,32 +447,41 @@ class _Trunk:
                 else:
                     self.g[(t, k)]["dout"].copy_(g)
         self.gmu_backward()
-        # gradient of every level-2 output (top GMU operand) and level-1 output (middle + top GMU operands)
+        # gradient of every level-2 output (top GMU operand) and level-1 output (middle + top GMU operands, and -- after the
+        # level-2 backward -- its key / value gradients): summed by grouped bpm_add_n launches into static buffers
         d2: Dict[str, torch.Tensor] = {}
         d1: Dict[str, torch.Tensor] = {}
-        dtm: Dict[Tuple[str, str], torch.Tensor] = {}
+        gmu_terms: Dict[str, List[torch.Tensor]] = {}
+        to_tmap = []
         for tgt in ("l", "a", "v"):
             l2a, l1a, l2b, l1b = FUSE[tgt]
             top, mid = self.g[(tgt, "top")], self.g[(tgt, "mid")]
             shp = (self.Ng[tgt], self.B, self.d)
             d2[l2a], d2[l2b] = top["dx1"].view(shp), top["dx2"].view(shp)
-            for name, gsum in ((l1a, top["dx1"] + mid["dx1"]), (l1b, top["dx2"] + mid["dx2"])):
+            for name, terms in ((l1a, [top["dx1"], mid["dx1"]]), (l1b, [top["dx2"], mid["dx2"]])):
                 if (tgt, name) in self.tmap:
-                    self.tmap[(tgt, name)]["dout"].copy_(gsum.view(shp))
+                    to_tmap.append(ops.addn_problem(self.tmap[(tgt, name)]["dout"], terms))
                 else:
-                    d1[name] = gsum.view(shp)
+                    gmu_terms[name] = terms
+        if to_tmap:
+            ops.add_n(to_tmap)
         self._time_backward()
         self._ready("fuse")
         for (tgt, name), t in self.tmap.items():
-            d1[name] = t["dh"]
+            gmu_terms[name] = [t["dh"]]
         dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2], self._layer_hook("level2"))
-        for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
-            if self.prune:                   # the GMU terms only touch rows 0 and N-1 of the level-1 output
+        if self.prune:                       # the GMU terms only touch rows 0 and N-1 of the level-1 output
+            for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
                 full = gk + gv
-                full.index_add_(0, self.idx[LEVEL1[src][0]], d1[src])
+                for t in gmu_terms[src]:
+                    full.index_add_(0, self.idx[LEVEL1[src][0]], t.view(2, self.B, self.d))
                 d1[src] = full
-            else:
-                d1[src] = d1[src] + gk + gv
+        else:
+            sums = []
+            for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
+                d1[src] = self.d1buf[src]
+                sums.append(ops.addn_problem(d1[src], gmu_terms[src] + [gk, gv]))
+            ops.add_n(sums)
         dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1], self._layer_hook("level1"))
         acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
@@ -470,8 +490,8 @@ class _Trunk:
         small: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, src, _)), gq in zip(LEVEL2.items(), dq2):
             (small if self.prune else acc)[q].append(gq)
-        for k, terms in acc.items():
-            torch.sum(torch.stack(terms), dim=0, out=self.dpx[k])
+        ops.add_n([ops.addn_problem(self.dpx[k], terms) for k, terms in acc.items()])
+        for k in acc:
             for gq in small[k]:
                 self.dpx[k].index_add_(0, self.idx[k], gq)
         res = self.conv_backward(seed, need_dx)
@@ -511,10 +531,14 @@ class _Trunk:
             ent["extra"] = torch.empty_like(extra) if extra is not None else None
             handle = self._seed_handle(seed)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._gpool):
-                self.forward(ent["in"], handle, training, prezero=fresh)
-                self.st._prezero_ev = None                    # (an event recorded while capturing means nothing outside)
-                ent["out"] = self.tail_forward(ent["extra"], handle, training)
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g, pool=self._gpool):
+                    self.forward(ent["in"], handle, training, prezero=fresh)
+                    self.st._prezero_ev = None                # (an event recorded while capturing means nothing outside)
+                    ent["out"] = self.tail_forward(ent["extra"], handle, training)
+            finally:
+                self._capturing = False
             ent["graph"] = g
             # host-side state a forward leaves for its backward (a replay runs no Python): restored before the backward
             ent["state"] = (self._conv, self._tail_desc, self.plan1._last, self.plan2._last)
@@ -524,6 +548,7 @@ class _Trunk:
             ent["extra"].copy_(extra)
         self._seed_handle(seed)
         ent["graph"].replay()
+        self._px_rows = {k: feats[k].shape[1] for k in ("l", "v", "a")}
         return ent["out"][0], ent["out"][1], key
 
     def restore_forward_state(self, fkey) -> None:

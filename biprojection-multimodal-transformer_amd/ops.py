@@ -265,6 +265,27 @@ def rows_cast(dtype, probs, seed=0) -> None:
         _lib.check(_lib.lib().bpm_rows_cast(dtype, sub, k, seed, _stream()), "bpm_rows_cast")
 
 
+def addn_problem(out, ins) -> "_lib.AddnProblem":
+    """out = sum(ins): contiguous fp32 tensors of one size (16-byte aligned); out may be one of them."""
+    p = _lib.AddnProblem()
+    n = out.numel()
+    if not 1 <= len(ins) <= 8:
+        raise ValueError("add_n takes 1 to 8 inputs")
+    for t in (out, *ins):
+        if t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+            raise ValueError("add_n: contiguous float32 tensors of one size")
+    p.out, p.n_in, p.count = _p(out), len(ins), n
+    for j, t in enumerate(ins):
+        p.src[j] = _p(t)
+    return p
+
+
+def add_n(probs) -> None:
+    arr = _as_array(_lib.AddnProblem, probs)
+    for sub, k in _chunks(arr, _lib.AddnProblem, None):
+        _lib.check(_lib.lib().bpm_add_n(sub, k, _stream()), "bpm_add_n")
+
+
 def gmu_problem(a1, a2, ag, x1, x2, R, *, out=None, dout=None, da1=None, da2=None, dag=None, ldg=0, dx1=None, dx2=None) -> GmuProblem:
     p = GmuProblem()
     p.a1, p.a2, p.ag, p.x1, p.x2 = (_f32(t, "gmu") for t in (a1, a2, ag, x1, x2))

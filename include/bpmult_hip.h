@@ -265,6 +265,17 @@ typedef struct bpm_gmu_problem {
     const float* dout; void* da1; void* da2; void* dag; int ldg; float* dx1; float* dx2;   /* backward */
     int R;
 } bpm_gmu_problem;
+/* out = sum of n_in fp32 tensors of `count` elements each (16-byte aligned pointers; out may alias an input).  The autograd sums where one tensor feeds several consumers (mmtr.py:779-847: a level-1 output is a Fusion-GMU
+ * operand twice and a level-2 key / value source; a projected input feeds up to eight encoders), grouped per launch. */
+#define BPM_ADDN_MAX 8
+typedef struct bpm_addn_problem {
+    float* out;
+    const float* src[8];    /* BPM_ADDN_MAX */
+    int n_in;
+    size_t count;
+} bpm_addn_problem;
+int bpm_add_n(const bpm_addn_problem* probs, int n, void* stream);
+
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 

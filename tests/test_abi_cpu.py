@@ -53,7 +53,8 @@ def _c_fields(struct_name):
                                        ("bpm_embed_problem", _lib.EmbedProblem), ("bpm_ln_problem", _lib.LnProblem),
                                        ("bpm_cast_problem", _lib.CastProblem), ("bpm_gmu_problem", _lib.GmuProblem),
                                        ("bpm_fold_desc", _lib.FoldDesc), ("bpm_unfold_desc", _lib.UnfoldDesc),
-                                       ("bpm_tail_desc", _lib.TailDesc), ("bpm_tail_grads", _lib.TailGrads)])
+                                       ("bpm_tail_desc", _lib.TailDesc), ("bpm_tail_grads", _lib.TailGrads),
+                                       ("bpm_addn_problem", _lib.AddnProblem)])
 def test_ctypes_structs_mirror_the_header(cname, cls):
     assert _c_fields(cname) == [f[0] for f in cls._fields_]
 
