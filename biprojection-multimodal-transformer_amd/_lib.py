@@ -116,6 +116,10 @@ class UnfoldDesc(C.Structure):
                 ("rows", C.c_int), ("cols", C.c_int), ("ldw", C.c_int), ("blk0", C.c_uint)]
 
 
+class ZeroDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("n", C.c_uint), ("blk0", C.c_uint)]
+
+
 class EmbedProblem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("T", C.c_int), ("B", C.c_int), ("accumulate", C.c_int),
                 ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("pos0", C.c_int), ("pos_stride", C.c_int)]
@@ -182,7 +186,9 @@ SIGNATURES = {
     "bpm_pack_rows_bwd": [C.POINTER(PackProblem), _I, _U64, _P],
     "bpm_pack_weights": [_I, _P, _I, C.c_uint, _P],
     "bpm_fold_bias": [C.c_void_p, _I, C.c_uint, _P],
-    "bpm_unfold_grads": [C.c_void_p, _I, C.c_uint, _P],
+    "bpm_unfold_grads": [C.c_void_p, _I, C.c_uint, _I, _P],
+    "bpm_zero_segment_blocks": [C.c_uint],
+    "bpm_zero_segments": [C.c_void_p, _I, C.c_uint, _P],
     "bpm_embed_pos_fwd": [C.POINTER(EmbedProblem), _I, _P, _I, _I, _F, _U64, _P],
     "bpm_embed_pos_bwd": [C.POINTER(EmbedProblem), _I, _I, _F, _U64, _P],
     "bpm_ln_fwd": [_I, C.POINTER(LnProblem), _I, _I, _F, _P],

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT) void fold_bias_kernel(const bpm_fold_desc* __re
 
 // gradients of the real parameters from the folded ones (see bpm_unfold_desc)
 constexpr int UNF_ROWS = 16;
-__global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc* __restrict__ tab, int ndesc) {
+__global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc* __restrict__ tab, int ndesc, int store_dw) {
     const bpm_unfold_desc d = find_desc(tab, ndesc, blockIdx.x);
     const int r0 = (int)(blockIdx.x - d.blk0) * UNF_ROWS, r1 = min(d.rows, r0 + UNF_ROWS);
     for (int c = threadIdx.x; c < d.cols; c += NT) {
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc*
         float ag = 0.f, ab = 0.f;
         for (int r = r0; r < r1; ++r) {
             const float f = d.dWf[(size_t)r * d.cols + c], w = d.W[(size_t)r * d.ldw + c], db = d.dbf[r];
-            d.dW[(size_t)r * d.ldw + c] += f * g + db * bt;
+            const float v = f * g + db * bt;
+            float* o = d.dW + (size_t)r * d.ldw + c;
+            *o = store_dw ? v : *o + v;                   // store_dw: this launch is the first writer of dW this step
             ag += f * w;
             ab += db * w;
         }
@@ -183,6 +185,20 @@ __global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc*
         atomicAdd(d.dbeta + c, ab);
     }
     if ((int)threadIdx.x < r1 - r0) d.dbias[r0 + threadIdx.x] += d.dbf[r0 + threadIdx.x];
+}
+
+// zero a list of fp32 segments (device-resident table): the small tensors of a flat gradient buffer whose large ones are
+// written by plain stores (see bpm_zero_segments)
+constexpr unsigned ZSEG = NT * 16;          // elements per block
+__global__ __launch_bounds__(NT) void zero_segments_kernel(const bpm_zero_desc* __restrict__ tab, int ndesc) {
+    const bpm_zero_desc d = find_desc(tab, ndesc, blockIdx.x);
+    const unsigned i0 = (blockIdx.x - d.blk0) * ZSEG, i1 = min(d.n, i0 + ZSEG);
+    if ((((uintptr_t)d.p) & 15) == 0) {
+        for (unsigned i = i0 + 4 * threadIdx.x; i + 3 < i1; i += 4 * NT) *(f32x4*)(d.p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (unsigned i = i0 + ((i1 - i0) & ~3u) + threadIdx.x; i < i1; i += NT) d.p[i] = 0.f;
+    } else {
+        for (unsigned i = i0 + threadIdx.x; i < i1; i += NT) d.p[i] = 0.f;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -866,9 +882,18 @@ extern "C" int bpm_fold_bias(const bpm_fold_desc* table_dev, int ndesc, unsigned
     return 0;
 }
 
-extern "C" int bpm_unfold_grads(const bpm_unfold_desc* table_dev, int ndesc, unsigned total_blocks, void* stream) {
+extern "C" int bpm_unfold_grads(const bpm_unfold_desc* table_dev, int ndesc, unsigned total_blocks, int store_dw, void* stream) {
     if (!table_dev || ndesc < 1 || total_blocks < 1) return BPM_ERR_ARG;
-    hipLaunchKernelGGL(unfold_grads_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, ndesc);
+    hipLaunchKernelGGL(unfold_grads_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, ndesc, store_dw);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bpm_zero_segment_blocks(unsigned n) { return (int)((n + ZSEG - 1) / ZSEG); }
+
+extern "C" int bpm_zero_segments(const bpm_zero_desc* table_dev, int ndesc, unsigned total_blocks, void* stream) {
+    if (!table_dev || ndesc < 1 || total_blocks < 1) return BPM_ERR_ARG;
+    hipLaunchKernelGGL(zero_segments_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, ndesc);
     BPM_CHECK_LAUNCH();
     return 0;
 }

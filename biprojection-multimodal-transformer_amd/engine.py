@@ -149,41 +149,41 @@ class ParamStore:
                 return p.grad is None
         return True
 
-    def prezero(self, force: bool = False) -> None:
-        """Called at the start of a training forward: if the gradients are unset now (the usual zero_grad /
-        `p.grad = None` step), clear the flat gradient buffer on the side stream while the forward pass runs, instead
-        of on the critical path when backward starts.  force: clear it in any case (a captured forward graph whose key
-        says the gradients start from zero), on the current stream when there is no side stream."""
-        self._prezero_ev = None
-        if not (force or self._fresh()):
-            return
-        if _SIDE:
-            main = torch.cuda.current_stream()
-            side = _side_stream(main.device, 1, self.side_low)
-            side.wait_stream(main)                      # the previous step's consumers of gflat (optimizer, all-reduce)
-            with torch.cuda.stream(side):
-                self.gflat.zero_()
-            self._prezero_ev = torch.cuda.Event()
-            self._prezero_ev.record(side)
-        elif force:
-            self.gflat.zero_()
+    def set_store_written(self, names) -> None:
+        """`names`: the parameters whose gradient the backward launch tables WRITE (plain store by their first
+        weight-gradient launch of a step) when the gradients start from zero -- the large encoder matrices.  Everything
+        else (biases, LayerNorm affines, Fusion-GMU / projection / unused parameters: sums of several launches, or
+        never written) is what begin_backward(stores=True) clears, through one table-driven launch."""
+        skip = set(names)
+        segs, cur = [], None
+        for n in self.names:                               # flat order: runs of consecutive other parameters (padding included)
+            a, b = self.off[n], self.off[n] + self.params[n].numel()
+            if n in skip:
+                if cur is not None:
+                    segs.append(tuple(cur))
+                cur = None
+            elif cur is None:
+                cur = [a, b]
+            else:
+                cur[1] = b
+        if cur is not None:
+            segs.append(tuple(cur))
+        base = self.gflat.data_ptr()
+        self._zero_table = ops.zero_table([(base + 4 * a, b - a) for a, b in segs]) if segs else None
+        self._store_written = skip
 
-    def begin_backward(self) -> None:
-        """Gradients accumulate into gflat like autograd accumulates into .grad:
-        a parameter whose .grad is None starts from zero."""
+    def begin_backward(self, stores: bool = False) -> bool:
+        """Gradients accumulate into gflat like autograd accumulates into .grad: a parameter whose .grad is None starts
+        from zero.  stores=True (the caller's launch tables have a first-writer-stores variant, set_store_written): when
+        the gradients are unset, only the small tensors are cleared and True is returned -- the caller must then run the
+        storing tables."""
         fresh = self._fresh()
-        ev = getattr(self, "_prezero_ev", None)
-        self._prezero_ev = None
-        if getattr(self, "_prezeroed", False):          # cleared by a captured forward graph (models/bpmult.py), same stream
-            self._prezeroed = False
-            if fresh:
-                return
-        if fresh and ev is not None:
-            torch.cuda.current_stream().wait_event(ev)  # already cleared during the forward pass
-        elif fresh:
+        if stores and fresh and getattr(self, "_zero_table", None) is not None:
+            ops.zero_segments(*self._zero_table)
+            return True
+        if fresh:
             self.gflat.zero_()
-        elif ev is not None:
-            raise RuntimeError("gradients were attached between forward and backward of one step")
+        return False
 
     def end_backward(self) -> None:
         for n in self.names:
@@ -471,7 +471,9 @@ class EncoderGroupPlan:
         self._side_low = d < 512
         self.store.side_low = self._side_low
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
-        self._bwd = {True: self._build_bwd(True), False: self._build_bwd(False)}
+        # backward tables by (training, stores): stores = the first weight-gradient launch of each large matrix writes
+        # instead of accumulating (the flat gradient buffer was not cleared: ParamStore.begin_backward(stores=True))
+        self._bwd = {(t, f): self._build_bwd(t, f) for t in (True, False) for f in (True, False)}
 
     # -- helpers ----------------------------------------------------------------
     def _mask_off(self, T: int, S: int) -> int:
@@ -596,7 +598,7 @@ class EncoderGroupPlan:
         elif fn is ops.ln_bwd:
             fn(s[1], s[2], self.dtype, seed)
         elif fn is ops.unfold_grads:
-            fn(s[1], s[2], s[3])
+            fn(s[1], s[2], s[3], s[4])
         else:
             raise RuntimeError("unknown step")
 
@@ -682,8 +684,9 @@ class EncoderGroupPlan:
         return [b["out"] for b in self.buf]
 
     # -- backward tables --------------------------------------------------------
-    def _build_bwd(self, training: bool):
+    def _build_bwd(self, training: bool, stores: bool = False):
         c, st, B, d, H = self.cfg, self.store, self.B, self.cfg.d, self.cfg.H
+        ACC1 = 0 if stores else F_ACCUM          # flags of the FIRST writer of a large weight gradient in a step
         ld, ld4, dh, dhp = self.ld, self.ld4, self.dh, self.dhp
         pr = (lambda p: p) if training else (lambda p: 0.0)
         A = ops.array
@@ -717,19 +720,21 @@ class EncoderGroupPlan:
                     dy0, dqs, dks, dvs = (b[n][par] for n in ("dy0", "dqs", "dks", "dvs"))
                 # ---- FFN
                 wg_ffn.append(ops.gemm_problem(dyf, b["h1"][i], GP("fc2.weight"), d, 4 * d, R, ld, ld4, 4 * d,
-                                               flags=F_ACCUM))
+                                               flags=ACC1))
                 dg_fc2.append(ops.gemm_problem(dyf, st.sptr(w2), dh1, R, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
                                                gate_scale=inv_relu, colsum=GP("fc1.bias"), out_kind=OUT_CT))
                 wg_ffn.append(ops.gemm_problem(dh1, b["xn2"][i], GP("fc1.weight"), 4 * d, d, R, ld4, ld, d,
-                                               flags=F_ACCUM))
+                                               flags=ACC1))
                 dg_fc1.append(ops.gemm_problem(dh1, st.sptr(w1), b["dxn"], R, d, 4 * d, ld4, ld, d))
                 lnf.append(ops.ln_problem(b["xmid"][i], P(f"layer_norms.{lnF}.weight"), None, stF[0], stF[1], R, dy=b["dxn"], ldy=d,
                                           add=dx, dx=dx, dgamma=GP(f"layer_norms.{lnF}.weight"), dbeta=GP(f"layer_norms.{lnF}.bias"),
                                           cast=dy, ldc=ld, cast_colsum=GP("self_attn.out_proj.bias"), drop_p=pr(c.res_dropout),
                                           drop_site=site(e.enc_id, i, S_RES1)))
                 # ---- (cross) attention block
+                # (cross-attention half: the first writer of out_proj.weight / in_proj_weight rows [0, d) on the side stream; the
+                # biprojection self-attention half below comes second and accumulates)
                 wg_att.append(ops.gemm_problem(dy, b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
-                                               flags=F_ACCUM))
+                                               flags=ACC1))
                 dg_out.append(ops.gemm_problem(dy, st.sptr(wo), dao, R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                heads=(B, H, e.T, dh, dhp)))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
@@ -743,7 +748,7 @@ class EncoderGroupPlan:
                 # per-layer scratch and are unfolded into in_proj / LayerNorm gradients by one launch at the end.
                 # (the bias column sums ride on the weight-gradient GEMMs: colsum_a, one extra MFMA against ones)
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
-                wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, R, ld, ld, d, flags=F_ACCUM,
+                wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, R, ld, ld, d, flags=ACC1,
                                                colsum_a=st.gptr(ipb_g, 0)))
                 wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][:d]))
                 wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][d:]))
@@ -766,9 +771,10 @@ class EncoderGroupPlan:
                                                    dh, dhp, self._mask_off(e.T, e.T), dO=b["dao0"], delta=b["delta0"], dQ=dqs,
                                                    lddq=3 * ld, dK=dks, lddk=3 * ld, dV=dvs, lddv=3 * ld, dq_scale=self.scale,
                                                    drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
+                    # in_proj_weight rows [d, 3d): this launch is their first writer (unfold_grads comes after it and adds)
                     for w, src in ((0, dqs), (1, dks), (2, dvs)):
-                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, 3 * ld, ld, d, flags=F_ACCUM,
-                                                      colsum_a=st.gptr(ipb_g, w * d)))
+                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, 3 * ld, ld, d,
+                                                      flags=F_ACCUM if w == 0 else ACC1, colsum_a=st.gptr(ipb_g, w * d)))
                     # d(xn) = dq Wq + dk Wk + dv Wv: three launches (plain store, then two +=) -- one owner per
                     # output tile in each launch, no atomics (per-lane-scattered float atomics run ~17x below store rate)
                     if ld == d:                                   # one product over K = 3d (see the dqkvs buffer)
@@ -812,7 +818,7 @@ class EncoderGroupPlan:
                          [(ops.ln_bwd, A(LnProblem, s_ln0), d)]
             # folded K/V gradients of this layer -> in_proj / LayerNorm parameter gradients; with it every gradient of
             # layer i is final once the side stream reaches MARK i and the main stream this point (all-reduce hook)
-            steps += [(SIDE, (ops.unfold_grads,) + self._unfold[i]), (MARK, i)]
+            steps += [(SIDE, (ops.unfold_grads,) + self._unfold[i] + (stores and not c.biprojection,)), (MARK, i)]
         # d(khat), d(vhat): all layers' dK / dV against the stacked projection weights, one product over K = L ld per
         # encoder; then -> d(embedded key / value source): LayerNorm backward without affine
         hat, dg_kv = [], []
@@ -824,10 +830,17 @@ class EncoderGroupPlan:
         steps += [(SIDE, self._gemm(GEMM_NN, dg_kv)), (SIDE, (ops.ln_bwd, A(LnProblem, hat), d)), JOIN]
         return steps
 
-    def backward(self, douts: Sequence[Optional[torch.Tensor]], on_layer=None):
+    @staticmethod
+    def store_written(prefix: str, layers: int):
+        """Names of the parameters whose gradient the `stores` tables write with a plain store (ParamStore.set_store_written)."""
+        return [f"{prefix}layers.{i}.{leaf}" for i in range(layers)
+                for leaf in ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "fc1.weight", "fc2.weight")]
+
+    def backward(self, douts: Sequence[Optional[torch.Tensor]], on_layer=None, stores: bool = False):
         """douts[e]: fp32 [T_e,B,d] gradient of encoder e's output (None = zero).  Returns the plan-owned
         gradients w.r.t. each encoder's query, key and value sources (three lists), and accumulates
-        parameter gradients into the ParamStore's flat gradient buffer."""
+        parameter gradients into the ParamStore's flat gradient buffer (stores=True: the large weight gradients are
+        WRITTEN by their first launch -- the buffer was not cleared, ParamStore.begin_backward(stores=True))."""
         seed, training = self._last
         c, st, B, d = self.cfg, self.store, self.B, self.cfg.d
         fin, keep = [], []
@@ -849,7 +862,7 @@ class EncoderGroupPlan:
             ops.ln_bwd(fin, d, self.dtype, seed)
         # on_layer(i, events): every parameter gradient of layer i (and, with the first call, of the final LayerNorm)
         # is complete once `events` have passed -- the data-parallel exchange starts there (distributed.GradSync)
-        self._run(self._bwd[training], seed, on_layer)
+        self._run(self._bwd[(training, stores)], seed, on_layer)
         p = c.embed_dropout if training else 0.0
         emb = []
         for e, b in zip(self.encs, self.buf):

@@ -348,15 +348,9 @@ class _Trunk:
         ops.gemm_grouped(self.dtype, GEMM_NN, dg2, 0)
 
     # -- whole trunk ------------------------------------------------------------------
-    def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool, prezero: Optional[bool] = None) -> List[torch.Tensor]:
+    def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> List[torch.Tensor]:
         """The caller has refreshed the weight shadows (ParamStore.refresh_shadows: a host-side decision, so it stays
-        outside a captured graph).  prezero: clear the flat gradient buffer on the side stream beside the forward pass
-        (None: when a backward will follow and the gradients are unset)."""
-        if prezero is None:
-            if training and getattr(self.m, "_want_grad", False):
-                self.st.prezero()
-        elif prezero:
-            self.st.prezero(force=True)
+        outside a captured graph)."""
         self.conv_forward(feats, seed, training)
         px = self.px
         q1 = [px[q] for (q, kv, _) in LEVEL1.values()]
@@ -429,13 +423,19 @@ class _Trunk:
         ops.tail_bwd(self._tail_desc, gr)
         return grads, tl["dextra"]
 
-    def backward(self, grads: Optional[Sequence[Optional[torch.Tensor]]], seed: int, need_dx: Dict[str, bool], begin: bool = True):
+    def backward(self, grads: Optional[Sequence[Optional[torch.Tensor]]], seed: int, need_dx: Dict[str, bool],
+                 stores: Optional[bool] = None):
         """grads: d(top_l), d(mid_l), d(top_a), d(mid_a), d(top_v), d(mid_v); None: the `dout` buffers of the GMU units
-        already hold them (written by tail_backward).  begin=False: the caller has dealt with the state of the flat
-        gradient buffer (captured graphs)."""
+        already hold them (written by tail_backward).  When the gradients are unset (zero_grad / `p.grad = None`) the flat
+        gradient buffer is NOT cleared as a whole: the encoders' large weight gradients are written by their first
+        launch (`stores` launch tables) and one table-driven launch clears the rest.  stores given (captured graphs: it is
+        part of the graph's key): the caller attaches the .grad views afterwards."""
         st = self.st
-        if begin:
-            st.begin_backward()
+        attach = stores is None
+        if stores is None:
+            stores = st.begin_backward(stores=True)
+        elif stores:
+            ops.zero_segments(*st._zero_table)
         it = iter(grads) if grads is not None else None
         for t in ("l", "a", "v"):
             for k in ("top", "mid"):
@@ -469,7 +469,7 @@ class _Trunk:
         self._ready("fuse")
         for (tgt, name), t in self.tmap.items():
             gmu_terms[name] = [t["dh"]]
-        dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2], self._layer_hook("level2"))
+        dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2], self._layer_hook("level2"), stores=stores)
         if self.prune:                       # the GMU terms only touch rows 0 and N-1 of the level-1 output
             for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
                 full = gk + gv
@@ -482,7 +482,7 @@ class _Trunk:
                 d1[src] = self.d1buf[src]
                 sums.append(ops.addn_problem(d1[src], gmu_terms[src] + [gk, gv]))
             ops.add_n(sums)
-        dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1], self._layer_hook("level1"))
+        dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1], self._layer_hook("level1"), stores=stores)
         acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
             acc[q].append(gq)
@@ -496,7 +496,7 @@ class _Trunk:
                 self.dpx[k].index_add_(0, self.idx[k], gq)
         res = self.conv_backward(seed, need_dx)
         self._ready("proj")
-        if begin:
+        if attach:
             st.end_backward()
         return res
 
@@ -518,8 +518,7 @@ class _Trunk:
     def graph_forward(self, feats: Dict[str, torch.Tensor], extra: Optional[torch.Tensor], seed: int, training: bool, want_grad: bool):
         """Forward pass through a captured graph when one exists (or can be captured now) for this key; returns
         (logits, z, key) or None (the caller then runs eagerly)."""
-        fresh = bool(want_grad and training and self.st._fresh())
-        key = (training, fresh, tuple(tuple(feats[k].shape) for k in ("l", "v", "a")), extra is not None)
+        key = (training, tuple(tuple(feats[k].shape) for k in ("l", "v", "a")), extra is not None)
         if getattr(self, "_fg", None) is None:
             self._fg, self._bg, self._gpool = {}, {}, torch.cuda.graph_pool_handle()
         ent = self._fg.setdefault(key, {"calls": 0})
@@ -534,8 +533,7 @@ class _Trunk:
             self._capturing = True
             try:
                 with torch.cuda.graph(g, pool=self._gpool):
-                    self.forward(ent["in"], handle, training, prezero=fresh)
-                    self.st._prezero_ev = None                # (an event recorded while capturing means nothing outside)
+                    self.forward(ent["in"], handle, training)
                     ent["out"] = self.tail_forward(ent["extra"], handle, training)
             finally:
                 self._capturing = False
@@ -556,14 +554,12 @@ class _Trunk:
         self._conv, self._tail_desc, self.plan1._last, self.plan2._last = self._fg[fkey]["state"]
 
     def graph_backward(self, fkey, dlogits: torch.Tensor, dz: Optional[torch.Tensor], params, seed: int, need: Dict[str, bool]):
-        """Backward of a graph-run forward.  The flat gradient buffer was cleared by that forward graph when the
-        gradients were unset (fkey[1]); otherwise this pass accumulates.  Returns (parameter gradients of the tail,
-        d(extra), d(features)) as clones of the graph's static outputs, or None before the key is captured."""
-        fresh = fkey[1]
+        """Backward of a graph-run forward.  Whether the gradients start from zero (first-writer-stores launch tables +
+        the small tensors cleared) or accumulate is part of the key.  Returns (parameter gradients of the tail, d(extra),
+        d(features)) as clones of the graph's static outputs, or None before the key is captured."""
         self.restore_forward_state(fkey)
-        if fresh != self.st._fresh():
-            return None                                       # .grad was attached / detached between forward and backward
-        key = (fkey, dz is not None, tuple(sorted(k for k, v in need.items() if v)))
+        fresh = self.st._fresh()
+        key = (fkey, fresh, dz is not None, tuple(sorted(k for k, v in need.items() if v)))
         ent = self._bg.setdefault(key, {"calls": 0})
         ent["calls"] += 1
         if "graph" not in ent:
@@ -575,7 +571,7 @@ class _Trunk:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._gpool):
                 pg, dextra = self.tail_backward(ent["dlogits"], ent["dz"], params)
-                res = self.backward(None, handle, need, begin=False)
+                res = self.backward(None, handle, need, stores=fresh)
             ent.update(graph=g, pg=pg, dextra=dextra, res=res)
         ent["dlogits"].copy_(dlogits)
         if dz is not None:
@@ -641,10 +637,6 @@ class _ModelFn(torch.autograd.Function):
         if ran is not None:
             pgrads, dextra, res = ran
         else:
-            if ctx.fkey is not None and ctx.fkey[1]:
-                if not ctx.trunk.st._fresh():
-                    raise RuntimeError("gradients were attached between forward and backward of one step")
-                ctx.trunk.st._prezeroed = True            # the forward GRAPH cleared the flat gradient buffer
             pgrads, dextra = ctx.trunk.tail_backward(dlogits, dz, ctx.params)
             res = ctx.trunk.backward(None, ctx.seed, ctx.need)
         return (None, res["l"], res["v"], res["a"], dextra.clone() if (dextra is not None and ctx.extra is not None) else None,
@@ -758,6 +750,7 @@ class _BPMulTBase(nn.Module):
                     w = getattr(self, lin).weight
                     st.add_shadow(lin + ".weight", lin + ".weight", w.shape[0], w.shape[1])
             st.finalize_shadows()
+            st.set_store_written([w for n in ENC_ORDER for w in EncoderGroupPlan.store_written(n + ".", self.layers)])
             self._store, self._trunks = st, {}
             self._anchor = torch.zeros(1, device=st.device, requires_grad=True)
         return self._store

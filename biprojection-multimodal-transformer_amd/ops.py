@@ -171,8 +171,24 @@ def fold_bias(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:
     _lib.check(_lib.lib().bpm_fold_bias(table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_fold_bias")
 
 
-def unfold_grads(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:
-    _lib.check(_lib.lib().bpm_unfold_grads(table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_unfold_grads")
+def unfold_grads(table_dev: torch.Tensor, ndesc: int, total_blocks: int, store_dw: bool = False) -> None:
+    _lib.check(_lib.lib().bpm_unfold_grads(table_dev.data_ptr(), ndesc, total_blocks, int(store_dw), _stream()), "bpm_unfold_grads")
+
+
+def zero_table(segments):
+    """[(device address, element count)] -> (device table, ndesc, total blocks) for zero_segments."""
+    L = _lib.lib()
+    descs, blk = [], 0
+    for ptr, n in segments:
+        z = _lib.ZeroDesc()
+        z.p, z.n, z.blk0 = ptr, n, blk
+        blk += L.bpm_zero_segment_blocks(n)
+        descs.append(z)
+    return device_table(descs), len(descs), blk
+
+
+def zero_segments(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:
+    _lib.check(_lib.lib().bpm_zero_segments(table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_zero_segments")
 
 
 def embed_problem(x, out, T, B, *, accumulate=False, drop_p=0.0, drop_site=0, pos0=0, pos_stride=1) -> EmbedProblem:

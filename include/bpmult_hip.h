@@ -190,7 +190,21 @@ typedef struct bpm_unfold_desc {
     int rows, cols, ldw;
     unsigned blk0;
 } bpm_unfold_desc;
-int bpm_unfold_grads(const bpm_unfold_desc* table_dev, int ndesc, unsigned total_blocks, void* stream);
+/* store_dw != 0: dW is WRITTEN (this launch is the first writer of those rows this step: no zero-fill, no read). */
+int bpm_unfold_grads(const bpm_unfold_desc* table_dev, int ndesc, unsigned total_blocks, int store_dw, void* stream);
+
+/* Zero a list of fp32 segments with one launch (device-resident table, built once).  A training step whose gradients
+ * start from zero (zero_grad / `p.grad = None`, train.py:384-385,396-398) does not clear the whole flat gradient buffer:
+ * the first weight-gradient GEMM of each large matrix stores instead of accumulating (no BPM_GEMM_ACCUM), and only
+ * the small tensors that are summed from several launches (biases, LayerNorm affines, ...) are cleared by this.
+ * blk0 = first block of the segment; a segment of n elements takes bpm_zero_segment_blocks(n) blocks. */
+typedef struct bpm_zero_desc {
+    float* p;
+    unsigned n;
+    unsigned blk0;
+} bpm_zero_desc;
+int bpm_zero_segment_blocks(unsigned n);
+int bpm_zero_segments(const bpm_zero_desc* table_dev, int ndesc, unsigned total_blocks, void* stream);
 
 /* Encoder prologue.  Replaces embed_scale * x + embed_positions(x[:,:,0]) and
  * F.dropout (transformer.py:66-79; position_embedding.py:8-27,62-76):

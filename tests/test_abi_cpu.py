@@ -54,7 +54,7 @@ def _c_fields(struct_name):
                                        ("bpm_cast_problem", _lib.CastProblem), ("bpm_gmu_problem", _lib.GmuProblem),
                                        ("bpm_fold_desc", _lib.FoldDesc), ("bpm_unfold_desc", _lib.UnfoldDesc),
                                        ("bpm_tail_desc", _lib.TailDesc), ("bpm_tail_grads", _lib.TailGrads),
-                                       ("bpm_addn_problem", _lib.AddnProblem)])
+                                       ("bpm_addn_problem", _lib.AddnProblem), ("bpm_zero_desc", _lib.ZeroDesc)])
 def test_ctypes_structs_mirror_the_header(cname, cls):
     assert _c_fields(cname) == [f[0] for f in cls._fields_]
 
@@ -76,7 +76,7 @@ def test_error_strings_and_argument_validation(lib):
     assert lib.bpm_attn_bwd_dq(_lib.BPM_BF16, C.byref(a), 1, 0, None) == -1
     assert lib.bpm_attn_bwd_dkv(_lib.BPM_BF16, C.byref(a), 1, 0, None) == -1
     assert lib.bpm_ln_bwd(_lib.BPM_F32, C.byref(ln), 1, 300, 0, None) == -1
-    assert lib.bpm_fold_bias(None, 1, 1, None) == -1 and lib.bpm_unfold_grads(None, 1, 1, None) == -1
+    assert lib.bpm_fold_bias(None, 1, 1, None) == -1 and lib.bpm_unfold_grads(None, 1, 1, 0, None) == -1
     assert lib.bpm_adam_step(None, None, None, None, 16, 1e-3, .9, .999, 1e-8, 0., 1, 1., 0, None) == -1
     assert lib.bpm_adam_step(16, 16, 16, 16, 6, 1e-3, .9, .999, 1e-8, 0., 1, 1., 0, None) == -1     # n % 4
     assert lib.bpm_adam_step(16, 16, 16, 20, 8, 1e-3, .9, .999, 1e-8, 0., 1, 1., 0, None) == -2     # alignment

@@ -108,7 +108,7 @@ def test_gradsync_two_ranks_equals_global_batch_gradient():
 @pytest.mark.parametrize("compress", ["none", "bf16"])
 def test_gradsync_rccl_two_gpus_with_accumulation(compress):
     """backend "nccl" (= RCCL), one GPU per rank: per-layer slice all-reduces on the communication stream gated by main- and
-    side-stream events, prezero on the side stream beside in-flight exchanges, one accumulation micro-step; fp32 slices
+    side-stream events, first-writer-stores launch tables beside in-flight exchanges, one accumulation micro-step; fp32 slices
     and bf16 copies (conftest.py runs these first wherever two GPUs are visible)."""
     world = 2
     port = _free_port()
