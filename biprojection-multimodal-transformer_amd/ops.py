@@ -31,10 +31,15 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# tests/test_plan_tables_cpu.py only: lets the launch TABLES (host logic: pointers, shapes, flags) be built from host
+# tensors without a GPU.  Nothing can be launched from them -- every bpm_* entry point needs device pointers.
+_DRY_RUN = False
+
+
 def _p(t) -> Optional[int]:
     if t is None or isinstance(t, int):     # raw device address (e.g. an offset into a flat buffer)
         return t
-    if not t.is_cuda:
+    if not t.is_cuda and not _DRY_RUN:
         raise ValueError("expected a CUDA (HIP) tensor: the BPMulT hot path has no CPU fallback")
     return t.data_ptr()
 
@@ -164,7 +169,8 @@ def pack_weights(dtype, table_dev: torch.Tensor, ndesc: int, total_blocks: int) 
 def device_table(descs) -> torch.Tensor:
     """ctypes descriptor structs -> one device-resident byte tensor (the table-driven launches read it on the GPU)."""
     arr = (type(descs[0]) * len(descs))(*descs)
-    return torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8).to("cuda")
+    t = torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8)
+    return t if _DRY_RUN else t.to("cuda")
 
 
 def fold_bias(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:

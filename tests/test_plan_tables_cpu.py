@@ -1,0 +1,67 @@
+"""Host logic without a GPU: the launch tables of the whole hot path (problem structs of every grouped launch of the
+forward and of both backward variants, weight-shadow / fold / unfold / zero-segment descriptor tables) build for the
+3-modal and the 4-modal model from HOST tensors (ops._DRY_RUN).  Nothing is launched -- this catches shape, flag and
+naming mistakes in the table builders before a GPU box is involved, and checks a few structural invariants."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import bpmult_amd  # noqa: F401
+from bpmult_amd import engine, ops
+from bpmult_amd._lib import F_ACCUM, GEMM_TN
+from bpmult_amd.models import get_model
+
+
+def _args(model, **kw):
+    a = dict(model=model, orig_d_l=32, orig_d_v=35, orig_d_a=74, orig_d_p=64, hidden_sz=64, vonly=True, lonly=True, aonly=True,
+             num_heads=4, layers=2, attn_dropout=0.1, attn_dropout_v=0., attn_dropout_a=0., relu_dropout=0.1, res_dropout=0.1,
+             out_dropout=0., embed_dropout=0.25, attn_mask=True, hybrid=False, n_classes=6, bert_model="unused",
+             text_features=True, precision="bf16", num_vectors_l=48, num_vectors_a=48, num_vectors_v=48)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+@pytest.fixture
+def dry_run():
+    ops._DRY_RUN = True
+    try:
+        yield
+    finally:
+        ops._DRY_RUN = False
+
+
+@pytest.mark.parametrize("model,kw", [("mmtrvat", {}), ("mmtrvat", {"hidden_sz": 40, "precision": "f32"}),
+                                      ("mmtrvapt", {"orig_d_a": 96, "num_vectors_a": 40, "num_vectors_v": 40}),
+                                      ("mmtrvapt", {"orig_d_a": 96, "hidden_sz": 40, "num_vectors_a": 40, "num_vectors_v": 40})])
+def test_launch_tables_build_from_host_tensors(dry_run, model, kw):
+    m = get_model(_args(model, **kw))
+    st = m._ensure_store()
+    trunk = m._trunk_for(2)
+    L = m.layers
+    for plan in (trunk.plan1, trunk.plan2):
+        assert set(plan._bwd) == {(t, f) for t in (True, False) for f in (True, False)}
+        for training in (True, False):
+            acc, sto = plan._bwd[(training, False)], plan._bwd[(training, True)]
+            assert len(acc) == len(sto)
+            n_first = 0
+            for a, s in zip(acc, sto):                       # same steps; only first-writer flags / the unfold mode differ
+                a, s = (a[1] if isinstance(a, tuple) and a[0] in (engine.SIDE, engine.SIDE2) else a), \
+                       (s[1] if isinstance(s, tuple) and s[0] in (engine.SIDE, engine.SIDE2) else s)
+                if isinstance(a, tuple) and a[0] is ops.gemm_grouped and a[2] == GEMM_TN:
+                    for pa, ps in zip(a[3], s[3]):
+                        assert pa.C == ps.C and (pa.flags & ~F_ACCUM) == (ps.flags & ~F_ACCUM)
+                        n_first += bool(pa.flags & F_ACCUM) and not (ps.flags & F_ACCUM)
+            # per encoder and layer: fc1.weight, fc2.weight, out_proj.weight, in_proj rows [0,d) (+ rows [d,3d) twice when a
+            # biprojection self-attention half writes them before unfold_grads)
+            per = 6 if plan.cfg.biprojection else 4
+            assert n_first == per * L * len(plan.encs), (n_first, per, L)
+        # every layer's dK / dV block sits inside the stacked buffer the merged data-gradient product reads
+        for b in plan.buf:
+            assert b["dkall"].shape == (b["Rk"], L * plan.ld) and b["Gk"].shape == (b["Rk"], plan.cfg.d)
+    # the zero list covers everything but the large encoder matrices, without overlapping them
+    tab, nd, nblk = st._zero_table
+    assert nd > 0 and nblk >= nd
+    big = sum(st.params[n].numel() for n in st._store_written)
+    assert big > 0.5 * sum(p.numel() for p in st.params.values())
+    assert all(n in st.params for n in st._store_written)
