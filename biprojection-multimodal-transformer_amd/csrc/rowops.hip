@@ -166,6 +166,9 @@ __global__ __launch_bounds__(NT) void fold_bias_kernel(const bpm_fold_desc* __re
 }
 
 // gradients of the real parameters from the folded ones (see bpm_unfold_desc)
+// (Measured in round 3 and not kept: per-block partial rows through a workspace + last-block sum instead of the float
+// atomics on dgamma / dbeta -- 72 us against 42 stand-alone at hidden 768: the 4-byte write-through stores cost more
+// than the contended atomics.)
 constexpr int UNF_ROWS = 16;
 __global__ __launch_bounds__(NT) void unfold_grads_kernel(const bpm_unfold_desc* __restrict__ tab, int ndesc, int store_dw) {
     const bpm_unfold_desc d = find_desc(tab, ndesc, blockIdx.x);
@@ -1007,7 +1010,9 @@ extern "C" int bpm_ln_bwd_ws(int dtype, const bpm_ln_problem* q, int n, int d, u
     hipStream_t s = (hipStream_t)stream;
     if (ln_vec_ok(q, n, d, true, dtype == BPM_BF16 ? 2 : 4)) {
         // two rows per wave and iteration: half the blocks of the scalar kernel
-        for (int i = 0; i < n; ++i) g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)q[i].R, 8, 128);
+        // at most 64 blocks per problem (= partial rows the last block sums): 128 took 78 / 98 us stand-alone at hidden 768,
+        // six problems (with parameter gradients / with the fused cast), 64 takes 72 / 88
+        for (int i = 0; i < n; ++i) g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)q[i].R, 8, 64);
         int maxw = d;
         bool sums = false;
         for (int i = 0; i < n; ++i) {
