@@ -360,6 +360,7 @@ def test_eval_mode_no_grad_and_state_dict_round_trip():
     assert float((out3 - ref).abs().max()) <= 1e-5
 
 
+@pytest.mark.skipif(os.environ.get("BPMULT_GRAPH", "1") == "0", reason="graph replay switched off by BPMULT_GRAPH=0")
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_graph_replay_equals_eager_launches(prec):
     """The step captured into hipGraphs (forward graph + backward graph per key, dropout seed read from device memory at
