@@ -26,6 +26,7 @@ BPM_F32, BPM_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
 F_ACCUM, F_RELU, F_ATOMIC, F_KPAD, F_BACKGROUND = 1, 2, 4, 8, 16     # F_KPAD = BPM_GEMM_KPAD_ZERO
+F_A_OVERLAP, F_B_OVERLAP = 32, 64                                     # BPM_GEMM_A_OVERLAP / _B_OVERLAP
 LN_OUT_F32 = 2
 MAX_GROUP = 18
 SEED_INDIRECT = 1 << 63          # seed = SEED_INDIRECT | device address of a uint64 (include/bpmult_hip.h)
@@ -199,8 +200,8 @@ SIGNATURES = {
     "bpm_add_n": [C.POINTER(AddnProblem), _I, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
-    "bpm_im2col1d": [_I, _P, _P, _I, _I, _I, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _P],
-    "bpm_col2im1d": [_P, _P, _I, _I, _I, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _I, _P],
+    "bpm_signal_pack": [_I, _P, _P, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _I, C.c_int64, _I, _P],
+    "bpm_signal_unpack": [_P, _P, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _I, _I, _P],
     "bpm_adaptive_pool1d_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "bpm_adaptive_pool1d_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "bpm_tail_fwd": [C.POINTER(TailDesc), _U64, _P],

@@ -1,18 +1,20 @@
 // Front-end of the 4-modal model that feeds the hot path (gfx950): AudioEncoder (mmtr.py:93-108) =
 // Conv1d(96, 96, k=128, stride 2) x 2 + AdaptiveAvgPool1d(200), SURVEY.md 8(f) rank 2.
 //
-// A 1-D convolution with a 128-tap kernel over 96 channels is a GEMM with K = 96 * 128 = 12288:
-//   y[(b,l), co] = sum_{ci,k} W[co, ci*128 + k] * x[b, ci, stride*l + k] + bias[co]
-// The products run on the grouped MFMA GEMM of this library (gemm.hip: forward NT, weight gradient TN with the bias
-// column sums, data gradient NN); this file holds what is specific to the convolution:
-//   bpm_im2col1d   : window rows  col[(b,l), ci*K + k] = x[b*sb + ci*sc + (stride*l + k)*sl]  (CT, leading dim padded)
-//                    -- arbitrary element strides, so the second layer reads the first layer's [(b,l), c] output
-//                    directly and nothing is transposed anywhere
-//   bpm_col2im1d   : its adjoint as a GATHER (no atomics): dx[b, ci, p] = sum over the <= K/stride windows that cover p
+// A strided 1-D convolution over a CHANNELS-LAST signal xc[(b, pos), ci] is a product whose left operand is the signal
+// itself read with overlapping rows: window l of a batch element is the contiguous run of taps*Cin elements that starts at
+// row stride*l, so
+//   y[(b,l), co] = sum_{k,ci} Wr[co, k*Cin + ci] * xc[(b, stride*l + k), ci] + bias[co]        (Wr = W with k major)
+// is bpm_gemm_grouped NT with lda = stride*Cin < K = taps*Cin (BPM_GEMM_A_OVERLAP), the weight gradient is TN with the
+// same buffer as the overlapping B operand, and the data gradient is the same form again over the zero-padded output
+// gradient (one problem per output phase pos % stride; frontend.py).  No window matrix exists anywhere (the explicit
+// one was taps/stride = 64x the signal: 2 x 86 MB per layer-1 call at batch 8).  This file holds what is left:
+//   bpm_signal_pack  : fp32 signal with arbitrary element strides -> CT channels-last rows, `front` zero rows ahead of
+//                      each batch element's L rows and zeros up to `rows_per_batch` / `total_rows`
+//   bpm_signal_unpack: fp32 rows [(b, l), c] (leading dim, rows per batch) -> fp32 signal with arbitrary strides
 //   bpm_adaptive_pool1d_{fwd,bwd}: AdaptiveAvgPool1d over the position axis of a [(b,l), c] matrix; the [B*out, C]
-//                    result IS the [B, 200, 96] tensor the model transposes to (mmtr.py:449)
-// All are streaming kernels (HBM-bound); an explicit window matrix costs 2 x 86 MB of traffic per layer-1 call at
-// batch 8 (35 us at HBM rate) against ~8 GFLOP of products.
+//                      result IS the [B, 200, 96] tensor the model transposes to (mmtr.py:449)
+// All are streaming kernels (HBM-bound) over signal-sized tensors.
 #include "bpm_common.h"
 #include "../../include/bpmult_hip.h"
 
@@ -20,42 +22,40 @@ namespace {
 
 constexpr int FNT = 256;
 
+// out[r, c .. c+3] for r < total_rows: row r = b * rows_per_batch + front + l with l < L takes x[b*sb + c*sc + l*sl], every
+// other row zeros.  One thread = 4 channels of one row (C % 4 == 0).
 template <typename CT>
-__global__ __launch_bounds__(FNT) void im2col1d_kernel(const float* __restrict__ x, CT* __restrict__ col, int B, int Cin, int K, int stride,
-                                                       int Lout, long sb, long sc, long sl, int ldcol) {
-    // one thread = 4 consecutive taps k of one (row, ci); K % 4 == 0
+__global__ __launch_bounds__(FNT) void signal_pack_kernel(const float* __restrict__ x, CT* __restrict__ out, int B, int C, int L, long sb, long sc, long sl,
+                                                          int front, int rows_per_batch, long total_rows, int ld) {
     const long idx = (long)blockIdx.x * FNT + threadIdx.x;
-    const int kq = K >> 2;
-    const long per_row = (long)Cin * kq;
-    const long rows = (long)B * Lout;
-    if (idx >= rows * per_row) return;
-    const long row = idx / per_row;
-    const int rem = (int)(idx % per_row), ci = rem / kq, k = (rem % kq) * 4;
-    const int b = (int)(row / Lout), l = (int)(row % Lout);
-    const float* p = x + b * sb + ci * sc + ((long)stride * l + k) * sl;
-    const float v0 = p[0], v1 = p[sl], v2 = p[2 * sl], v3 = p[3 * sl];
-    CT* o = col + row * ldcol + ci * K + k;
+    const int cq = C >> 2;
+    if (idx >= total_rows * cq) return;
+    const long row = idx / cq;
+    const int c = (int)(idx % cq) * 4;
+    const long b = row / rows_per_batch;
+    const int l = (int)(row % rows_per_batch) - front;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (b < B && l >= 0 && l < L) {
+        const float* p = x + b * sb + c * sc + (long)l * sl;
+        v0 = p[0]; v1 = p[sc]; v2 = p[2 * sc]; v3 = p[3 * sc];
+    }
+    CT* o = out + row * ld + c;
     if constexpr (sizeof(CT) == 4) *(f32x4*)o = f32x4{v0, v1, v2, v3};
     else { bf16x4 t; t[0] = (bf16_t)v0; t[1] = (bf16_t)v1; t[2] = (bf16_t)v2; t[3] = (bf16_t)v3; *(bf16x4*)o = t; }
 }
 
-// dx[b, ci, p] (+)= sum_{l : 0 <= p - stride*l < K, l < Lout} dcol[(b,l), ci*K + p - stride*l]
-__global__ __launch_bounds__(FNT) void col2im1d_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int Cin, int K, int stride,
-                                                       int Lout, int Lin, long sb, long sc, long sl, int ldcol, int accumulate) {
+// x[b*sb + c*sc + l*sl] = l < Lvalid ? src[(b * rows_per_batch + l) * ld + c] : 0     for l < L
+__global__ __launch_bounds__(FNT) void signal_unpack_kernel(const float* __restrict__ src, float* __restrict__ x, int B, int C, int L, long sb, long sc, long sl,
+                                                            int Lvalid, int rows_per_batch, int ld) {
     const long idx = (long)blockIdx.x * FNT + threadIdx.x;
-    if (idx >= (long)B * Cin * Lin) return;
-    const int p = (int)(idx % Lin), ci = (int)((idx / Lin) % Cin), b = (int)(idx / ((long)Lin * Cin));
-    int lhi = p / stride;
-    if (lhi > Lout - 1) lhi = Lout - 1;
-    int llo = (p - K + stride) / stride;                 // smallest l with p - stride*l <= K - 1
-    if (p - K + 1 <= 0) llo = 0;
-    float s = 0.f;
-    for (int l = llo; l <= lhi; ++l) {
-        const int k = p - stride * l;
-        if (k >= 0 && k < K) s += dcol[((long)b * Lout + l) * ldcol + ci * K + k];
-    }
-    float* o = dx + b * sb + ci * sc + (long)p * sl;
-    *o = accumulate ? *o + s : s;
+    const int cq = C >> 2;
+    if (idx >= (long)B * L * cq) return;
+    const int c = (int)(idx % cq) * 4, l = (int)((idx / cq) % L);
+    const long b = idx / ((long)cq * L);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (l < Lvalid) v = *(const f32x4*)(src + (b * rows_per_batch + l) * ld + c);
+    float* p = x + b * sb + c * sc + (long)l * sl;
+    p[0] = v[0]; p[sc] = v[1]; p[2 * sc] = v[2]; p[3 * sc] = v[3];
 }
 
 BPM_DEV void pool_window(int i, int Lin, int Lout, int& lo, int& hi) {       // torch adaptive pooling: [floor(i L / O), ceil((i+1) L / O))
@@ -95,28 +95,28 @@ __global__ __launch_bounds__(FNT) void pool_bwd_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int bpm_im2col1d(int dtype, const float* x, void* col, int B, int Cin, int K, int stride, int Lin, int Lout,
-                            int64_t sb, int64_t sc, int64_t sl, int ldcol, void* stream) {
-    if (!x || !col || B < 1 || Cin < 1 || K < 4 || (K & 3) || stride < 1 || Lout < 1 || ldcol < Cin * K) return BPM_ERR_ARG;
-    if ((long)stride * (Lout - 1) + K > Lin) return BPM_ERR_ARG;
+extern "C" int bpm_signal_pack(int dtype, const float* x, void* out, int B, int C, int L, int64_t sb, int64_t sc, int64_t sl,
+                               int front, int rows_per_batch, int64_t total_rows, int ld, void* stream) {
+    if (!x || !out || B < 1 || C < 4 || (C & 3) || L < 1 || front < 0 || rows_per_batch < front + L || ld < C) return BPM_ERR_ARG;
+    if (total_rows < (int64_t)B * rows_per_batch) return BPM_ERR_ARG;
     if (dtype != BPM_F32 && dtype != BPM_BF16) return BPM_ERR_ARG;
-    if (((uintptr_t)col & 15) || (ldcol & 3)) return BPM_ERR_ALIGN;
-    const long n = (long)B * Lout * Cin * (K >> 2);
+    if (((uintptr_t)out & 15) || (ld & 3)) return BPM_ERR_ALIGN;
+    const long n = (long)total_rows * (C >> 2);
     const dim3 grid((unsigned)((n + FNT - 1) / FNT));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == BPM_BF16) hipLaunchKernelGGL(im2col1d_kernel<bf16_t>, grid, dim3(FNT), 0, s, x, (bf16_t*)col, B, Cin, K, stride, Lout, sb, sc, sl, ldcol);
-    else hipLaunchKernelGGL(im2col1d_kernel<float>, grid, dim3(FNT), 0, s, x, (float*)col, B, Cin, K, stride, Lout, sb, sc, sl, ldcol);
+    if (dtype == BPM_BF16) hipLaunchKernelGGL(signal_pack_kernel<bf16_t>, grid, dim3(FNT), 0, s, x, (bf16_t*)out, B, C, L, sb, sc, sl, front, rows_per_batch, total_rows, ld);
+    else hipLaunchKernelGGL(signal_pack_kernel<float>, grid, dim3(FNT), 0, s, x, (float*)out, B, C, L, sb, sc, sl, front, rows_per_batch, total_rows, ld);
     BPM_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int bpm_col2im1d(const float* dcol, float* dx, int B, int Cin, int K, int stride, int Lin, int Lout,
-                            int64_t sb, int64_t sc, int64_t sl, int ldcol, int accumulate, void* stream) {
-    if (!dcol || !dx || B < 1 || Cin < 1 || K < 1 || stride < 1 || Lout < 1 || Lin < 1 || ldcol < Cin * K) return BPM_ERR_ARG;
-    if ((long)stride * (Lout - 1) + K > Lin) return BPM_ERR_ARG;
-    const long n = (long)B * Cin * Lin;
-    hipLaunchKernelGGL(col2im1d_kernel, dim3((unsigned)((n + FNT - 1) / FNT)), dim3(FNT), 0, (hipStream_t)stream, dcol, dx, B, Cin, K, stride,
-                       Lout, Lin, sb, sc, sl, ldcol, accumulate);
+extern "C" int bpm_signal_unpack(const float* src, float* x, int B, int C, int L, int64_t sb, int64_t sc, int64_t sl,
+                                 int Lvalid, int rows_per_batch, int ld, void* stream) {
+    if (!src || !x || B < 1 || C < 4 || (C & 3) || L < 1 || Lvalid < 0 || Lvalid > L || rows_per_batch < Lvalid || ld < C) return BPM_ERR_ARG;
+    if (((uintptr_t)src & 15) || (ld & 3)) return BPM_ERR_ALIGN;
+    const long n = (long)B * L * (C >> 2);
+    hipLaunchKernelGGL(signal_unpack_kernel, dim3((unsigned)((n + FNT - 1) / FNT)), dim3(FNT), 0, (hipStream_t)stream, src, x, B, C, L, sb, sc, sl,
+                       Lvalid, rows_per_batch, ld);
     BPM_CHECK_LAUNCH();
     return 0;
 }

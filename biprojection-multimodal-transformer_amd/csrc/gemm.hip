@@ -617,8 +617,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
         // tight descriptors (see desc_bytes in gemm_dma.h): whole k stages of a k-contiguous row, whole chunks of a k-strided one
         constexpr int E = Tr<CT>::EPC;
         const int kceil = (Kb + BK - 1) / BK * BK;
-        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)Xp, 0, ((XK ? Mb : Kb) - 1) * ldx * (int)sizeof(CT) + min(XK ? kceil : (Mb + E - 1) / E * E, ldx) * (int)sizeof(CT), 0x00020000);
-        rsy = __builtin_amdgcn_make_buffer_rsrc((void*)Yp, 0, ((YK ? Nb : Kb) - 1) * ldy * (int)sizeof(CT) + min(YK ? kceil : (Nb + E - 1) / E * E, ldy) * (int)sizeof(CT), 0x00020000);
+        // (an operand whose rows overlap, BPM_GEMM_x_OVERLAP, owns its last row's full length past the leading dimension)
+        const int wx = XK ? kceil : (Mb + E - 1) / E * E, wy = YK ? kceil : (Nb + E - 1) / E * E;
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)Xp, 0, ((XK ? Mb : Kb) - 1) * ldx * (int)sizeof(CT) + ((P.flags & BPM_GEMM_A_OVERLAP) ? wx : min(wx, ldx)) * (int)sizeof(CT), 0x00020000);
+        rsy = __builtin_amdgcn_make_buffer_rsrc((void*)Yp, 0, ((YK ? Nb : Kb) - 1) * ldy * (int)sizeof(CT) + ((P.flags & BPM_GEMM_B_OVERLAP) ? wy : min(wy, ldy)) * (int)sizeof(CT), 0x00020000);
         SX::voffsets(ldx, m0, tid, vx);
         SY::voffsets(ldy, n0, tid, vy);
         stepx = SX::stage_step(ldx);
@@ -840,16 +842,21 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     const bool xk = variant != BPM_GEMM_TN, yk = variant == BPM_GEMM_NT;
     // hardware-bounded loader: every problem promises zero k padding, k-contiguous rows are whole k stages and the
     // matrices fit 31-bit byte offsets
-    bool fast = true;
+    bool fast = true, overlap = false;
     for (int i = 0; i < nprob && fast; ++i) {
         const bpm_gemm_problem& q = probs[i];
         const int stage_b = 64 * (variant == BPM_GEMM_NT ? KS_FWD : 1);
+        const bool aov = (q.flags & BPM_GEMM_A_OVERLAP) != 0, bov = (q.flags & BPM_GEMM_B_OVERLAP) != 0;
+        overlap = overlap || aov || bov;
         fast = (q.flags & BPM_GEMM_KPAD_ZERO) != 0;
-        if (xk) fast = fast && ((long)q.lda * sz) % stage_b == 0 && (long)q.K <= q.lda;
-        if (yk) fast = fast && ((long)q.ldb * sz) % stage_b == 0 && (long)q.K <= q.ldb;
-        const long bx = (long)(xk ? q.M : q.K) * q.lda * sz, by = (long)(yk ? q.N : q.K) * q.ldb * sz;
+        // overlapping rows: no zero padding behind a row (the next window starts there), so k must end on a stage
+        if (xk) fast = fast && (aov ? q.K % 64 == 0 : ((long)q.lda * sz) % stage_b == 0 && (long)q.K <= q.lda);
+        if (yk) fast = fast && (bov ? q.K % 64 == 0 : ((long)q.ldb * sz) % stage_b == 0 && (long)q.K <= q.ldb);
+        const long bx = ((long)(xk ? q.M : q.K) - 1) * q.lda * sz + (long)(aov ? (xk ? q.K : q.M) : q.lda) * sz;
+        const long by = ((long)(yk ? q.N : q.K) - 1) * q.ldb * sz + (long)(bov ? (yk ? q.K : q.N) : q.ldb) * sz;
         fast = fast && bx < (1l << 31) - 65536 && by < (1l << 31) - 65536;
     }
+    if (overlap && !fast) return BPM_ERR_ARG;      // only the hardware-bounded loaders address overlapping rows
     // LDS-DMA kernel (gemm_dma.h): bf16, no split-K, k-contiguous operands hold whole 128-byte stages inside their
     // zero-padded rows, epilogue 4-wide.  Measured on MI355X at hidden 768, six problems of 4096 rows per launch
     // (tools/gemm_lab.py, us, register-staged 128 x 64 kernel -> the configuration chosen below): q 84 -> 55, k/v 154 ->
@@ -863,7 +870,8 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         for (int i = 0; i < nprob && legal; ++i) {
             const bpm_gemm_problem& q = probs[i];
             const long kceil = ((long)q.K + DK - 1) / DK * DK;
-            legal = q.splitk <= 1 && !(q.flags & BPM_GEMM_ATOMIC) && (!xk || kceil <= q.lda) && (!yk || kceil <= q.ldb);
+            legal = q.splitk <= 1 && !(q.flags & BPM_GEMM_ATOMIC) && (!xk || (q.flags & BPM_GEMM_A_OVERLAP) || kceil <= q.lda) &&
+                    (!yk || (q.flags & BPM_GEMM_B_OVERLAP) || kceil <= q.ldb);
             // its epilogue is the 4-wide one only (epi_fast_ok, evaluated here on the host)
             const uintptr_t al = (uintptr_t)q.bias_n | (uintptr_t)q.resid | (uintptr_t)q.C | (uintptr_t)q.gate;
             legal = legal && (q.N & 3) == 0 && (al & 15) == 0 && ((q.ldr | q.ldc | q.ldg) & 3) == 0 && !q.bias_m &&

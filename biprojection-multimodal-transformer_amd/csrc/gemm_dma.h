@@ -37,10 +37,18 @@
 #ifndef BPM_DMA_ABLATE
 #define BPM_DMA_ABLATE 0      // lab builds only (tools/gemm_lab.py): 1 no MFMA, 2 no DMA in the loop, 4 no epilogue
 #endif
+#ifdef BPM_GEMM_TRACE
+// diagnostic build only (tools/gemm_clock_probe.py): slot <- shader-clock counter, slot + 1 <- 100 MHz realtime counter
+#define BPM_TRACE_CLK(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { \
+        g_trace[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        g_trace[blockIdx.x * 16 + (slot) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define BPM_TRACE_CLK(slot) do { } while (0)
+#endif
 constexpr int DK = 64;                     // k elements per stage
 constexpr int DROW = 128;                  // bytes of k per row-image row
 
-BPM_DEV int desc_bytes(int rows, int ld, int width, int sz) { return ((rows - 1) * ld + min(width, ld)) * sz; }
+BPM_DEV int desc_bytes(int rows, int ld, int width, int sz, bool overlap = false) { return ((rows - 1) * ld + (overlap ? width : min(width, ld))) * sz; }
 
 BPM_DEV int dma_row_off(int row, int c) { return row * DROW + ((c ^ ((row >> 1) & 7)) << 4); }
 BPM_DEV int dma_col_off(int krow, int ch) { return krow * 256 + ((ch ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4); }
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WND, wn = wave % WND;
 
+    BPM_TRACE_CLK(0);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const Prob& P = pick_problem(grp, bid);
     if (BPM_BASE_PRIO && XK && !(P.flags & BPM_GEMM_BACKGROUND)) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
@@ -258,8 +267,8 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     // descriptor = exactly the bytes the operand owns: (rows - 1) leading dimensions plus the last row's width (whole k
     // stages of a k-contiguous row, whole 16-byte chunks of a k-strided one) -- an operand that is a COLUMN VIEW of a wider
     // buffer then never reads past the parent's last row (rows * ld from the view's first element would)
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, desc_bytes(XK ? P.M : P.K, P.ldx, XK ? nkt * DK : (P.M + 7) & ~7, 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, desc_bytes(YK ? P.N : P.K, P.ldy, YK ? nkt * DK : (P.N + 7) & ~7, 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, desc_bytes(XK ? P.M : P.K, P.ldx, XK ? nkt * DK : (P.M + 7) & ~7, 2, (P.flags & BPM_GEMM_A_OVERLAP) != 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, desc_bytes(YK ? P.N : P.K, P.ldy, YK ? nkt * DK : (P.N + 7) & ~7, 2, (P.flags & BPM_GEMM_B_OVERLAP) != 0), 0x00020000);
     const int vx = SX::voffset(P.ldx, m0, wave, lane), vy = SY::voffset(P.ldy, n0, wave, lane);
     const int stepx = SX::stage_step(P.ldx), stepy = SY::stage_step(P.ldy);
     const int ldx = P.ldx, ldy = P.ldy;
@@ -296,6 +305,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     int buf = 0;
 #pragma unroll 1
     for (int kt = 0; kt < nkt; ++kt) {
+        if (kt == 1) BPM_TRACE_CLK(2);                               // first stage consumed: the pipeline is full
         // stage kt has landed once at most the younger stages' DMAs are outstanding (this wave's share), and for the
         // other waves' shares once every wave has passed the barrier behind that wait
         if (NS == 3 && kt + 1 < nkt) dma_wait<LPS>();
@@ -341,6 +351,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
     dma_wait<0>();                         // nothing of ours may still be writing LDS when the workgroup retires
+    BPM_TRACE_CLK(4);
 
     const int r = lane & 15, g = lane >> 4;
     const int mw = m0 + wm * WROWS;
@@ -406,4 +417,8 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     pass(std::integral_constant<int, 4>{});
     static_assert(TMW <= 10, "passes unrolled for up to 160 rows per wave");
     if (P.colsum) flush_colsum_wide(P, cs, nbw, lane);
+#ifdef BPM_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BPM_TRACE_CLK(6);
+#endif
 }

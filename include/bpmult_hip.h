@@ -68,7 +68,15 @@ enum { BPM_OUT_F32 = 0, BPM_OUT_CT = 1, BPM_OUT_HEADS = 2 };
 /* BPM_GEMM_BACKGROUND: this product is off the caller's critical path (weight gradients, work put on a side
  * stream).  Forward / data-gradient products otherwise raise their waves' issue priority (s_setprio) so that, when
  * kernels of two streams share a CU, the critical-path kernel is served first. */
-enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4, BPM_GEMM_KPAD_ZERO = 8, BPM_GEMM_BACKGROUND = 16 };
+/* BPM_GEMM_A_OVERLAP / BPM_GEMM_B_OVERLAP: the rows of that operand OVERLAP in memory -- its leading dimension is
+ * smaller than its row length (K of a k-contiguous operand, M / N of a k-strided one).  Row r is still the elements
+ * [r*ld, r*ld + length): the sliding windows of a strided 1-D convolution over a channels-last signal are exactly such
+ * a matrix (ld = stride*Cin, length = taps*Cin), so the convolution and its two gradients are products on the signal
+ * itself and no window matrix is materialised (frontend.py; reference mmtr.py:93-108).  Needs BPM_GEMM_KPAD_ZERO
+ * (hardware-bounded loads only: the operand must be readable up to (rows-1)*ld + length), and K % 64 == 0 when the
+ * overlapping operand is k-contiguous (its k tail would otherwise read the next window's data instead of zeros). */
+enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4, BPM_GEMM_KPAD_ZERO = 8, BPM_GEMM_BACKGROUND = 16,
+       BPM_GEMM_A_OVERLAP = 32, BPM_GEMM_B_OVERLAP = 64 };
 
 typedef struct bpm_gemm_problem {
     const void* A;          /* CT */
@@ -294,15 +302,19 @@ int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);
 
 /* Front-end: AudioEncoder of the 4-modal model (mmtr.py:93-108: Conv1d(96,96,k=128,stride 2) x 2 + AdaptiveAvgPool1d(200)).
- * A convolution is computed as a product over window rows with bpm_gemm_grouped:
- *   col[(b,l), ci*K + k] = x[b*sb + ci*sc + (stride*l + k)*sl]      (bpm_im2col1d; x fp32 with element strides, col CT [B*Lout, ldcol])
- *   y[(b,l), co] = col . W[co, :]^T + bias                          (NT; weight gradient TN + colsum_a, data gradient NN)
- *   dx[b, ci, p] = sum of the window entries that cover p           (bpm_col2im1d: gather, `accumulate` != 0 adds)
+ * A strided convolution over a channels-last signal xc[(b,pos), ci] is bpm_gemm_grouped on the signal itself, its rows
+ * read overlapping (BPM_GEMM_A_OVERLAP / _B_OVERLAP; no window matrix):
+ *   y[(b,l), co] = sum_{k,ci} Wr[co, k*Cin + ci] xc[(b, stride*l + k), ci] + bias     NT, lda = stride*Cin, K = taps*Cin
+ *   dWr = dy^T . windows (TN, the signal as overlapping B; + colsum_a = bias gradient);   dx: the same NT form over the
+ *   zero-padded dy, one problem per output phase pos % stride.
+ * bpm_signal_pack:   out[r, c] (CT, leading dim ld, r < total_rows): row r = b*rows_per_batch + front + l, l < L, takes
+ *                    x[b*sb + c*sc + l*sl] (fp32, element strides); every other row is zeros.  C % 4 == 0.
+ * bpm_signal_unpack: x[b*sb + c*sc + l*sl] = l < Lvalid ? src[(b*rows_per_batch + l)*ld + c] : 0 for l < L (fp32 both).
  * bpm_adaptive_pool1d_*: torch.nn.AdaptiveAvgPool1d over the position axis of a fp32 [(b,l), C] matrix -> [(b,i), C]. */
-int bpm_im2col1d(int dtype, const float* x, void* col, int B, int Cin, int K, int stride, int Lin, int Lout,
-                 int64_t sb, int64_t sc, int64_t sl, int ldcol, void* stream);
-int bpm_col2im1d(const float* dcol, float* dx, int B, int Cin, int K, int stride, int Lin, int Lout,
-                 int64_t sb, int64_t sc, int64_t sl, int ldcol, int accumulate, void* stream);
+int bpm_signal_pack(int dtype, const float* x, void* out, int B, int C, int L, int64_t sb, int64_t sc, int64_t sl,
+                    int front, int rows_per_batch, int64_t total_rows, int ld, void* stream);
+int bpm_signal_unpack(const float* src, float* x, int B, int C, int L, int64_t sb, int64_t sc, int64_t sl,
+                      int Lvalid, int rows_per_batch, int ld, void* stream);
 int bpm_adaptive_pool1d_fwd(const float* y, float* out, int B, int C, int Lin, int Lout, void* stream);
 int bpm_adaptive_pool1d_bwd(const float* dout, float* dy, int B, int C, int Lin, int Lout, void* stream);
 

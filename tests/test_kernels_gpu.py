@@ -190,6 +190,42 @@ def test_gemm_large_tile_epilogues_match_small_tile():
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("N", [96, 512])
+def test_gemm_operands_with_overlapping_rows(dtype, N):
+    """BPM_GEMM_A_OVERLAP / _B_OVERLAP: an operand whose leading dimension is smaller than its row length -- the sliding
+    windows of a strided convolution over a channels-last signal (frontend.py).  NT with the overlapping A (N = 96: the
+    128 x 64 kernel; N = 512: the LDS-DMA kernel in bf16) and TN with the same buffer as the overlapping B, against fp64 on
+    the explicitly unfolded windows; the plain-pointer loaders refuse the flags."""
+    from bpmult_amd._lib import F_A_OVERLAP, F_B_OVERLAP
+    ct = torch.bfloat16 if dtype == BPM_BF16 else torch.float32
+    C, taps, stride, L = 32, 16, 2, 1030
+    K, ld = taps * C, stride * C                       # 512-element windows every 64 elements
+    M = (L - taps) // stride + 1
+    sig = rnd(L * C, seed=31).to(ct).to(DEV)
+    win = torch.stack([sig[r * ld:r * ld + K] for r in range(M)]).double().cpu()          # [M, K]
+    W = rnd(N, K, seed=32, scale=K ** -0.5).to(ct).to(DEV)
+    bias = rnd(N, seed=33).to(DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_grouped(dtype, GEMM_NT, [ops.gemm_problem(sig, W, out, M, N, K, ld, K, N, bias_n=bias, flags=ops.F_KPAD | F_A_OVERLAP)])
+    torch.cuda.synchronize()
+    close(out, win @ W.double().cpu().T + bias.double().cpu(), 1e-4 if dtype == BPM_F32 else 2e-3, "NT, overlapping A")
+    # TN: dW[n, (k,c)] = sum_r dy[r, n] window_r -- k extent padded to 64 rows of zeros in dy; the signal readable behind them
+    Mp = (M + 63) // 64 * 64
+    sig2 = torch.zeros((Mp - 1) * ld + K, device=DEV, dtype=ct)
+    sig2[:L * C] = sig
+    dy = torch.zeros(Mp, N, device=DEV, dtype=ct)
+    dy[:M] = rnd(M, N, seed=34).to(ct).to(DEV)
+    dW = torch.full((N, K), float("nan"), device=DEV)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm_grouped(dtype, GEMM_TN, [ops.gemm_problem(dy, sig2, dW, N, K, Mp, N, ld, K, flags=ops.F_KPAD | F_B_OVERLAP, colsum_a=cs)])
+    torch.cuda.synchronize()
+    close(dW, dy[:M].double().cpu().T @ win, 1e-4 if dtype == BPM_F32 else 3e-3, "TN, overlapping B")
+    close(cs, dy[:M].double().cpu().sum(0), 1e-4 if dtype == BPM_F32 else 2e-3, "TN column sums")
+    with pytest.raises(RuntimeError):                  # without the zero-padding promise there is no hardware-bounded loader
+        ops.gemm_grouped(dtype, GEMM_NT, [ops.gemm_problem(sig, W, out, M, N, K, ld, K, N, flags=F_A_OVERLAP)])
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_gemm_nn_tn_and_splitk(dtype):
     M, N, K = 300, 140, 200          # dgrad: dx[M,K'] = dy[M,N'] W[N',K']; here generic names
     A, Ar = to_ct(rnd(M, K, seed=5), dtype)
