@@ -30,6 +30,8 @@
 // compare against a per-lane limit and is skipped altogether on tiles that a
 // wave-uniform test proves fully visible; dropout hashing runs only when
 // enabled; exponentials are raw v_exp_f32.
+#include <type_traits>
+
 #include "bpm_common.h"
 #include "bpm_prof.h"
 #include "../../include/bpmult_hip.h"
@@ -568,6 +570,7 @@ BPM_DEV void attn_bwd_dkv_block(const AProb& P, const DropCfg& drop, char* smem,
     const int qt_lo = i_first / QT;
     const int qt_hi = (P.T + QT - 1) / QT;
     const bool dropping = drop.thresh != 0;
+    const bool pair_ok = (P.S & 3) == 0;               // row starts are multiples of 4: keys (4m .. 4m+3) are one hash quad
 
     RowStage<CT, DHP, QT> qst, dost;
     float n_lse = 0.f, n_del = 0.f;                    // threads < QT: next tile's -lse*log2(e) and delta
@@ -619,9 +622,30 @@ BPM_DEV void attn_bwd_dkv_block(const AProb& P, const DropCfg& drop, char* smem,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
                 if (dropping) {
+                    if (pair_ok) {
+                        // Element (query ib + r, key j) is 16-bit lane j & 3 of the hash quad (query, j >> 2) -- the quads the
+                        // forward / dQ kernels draw once per four KEYS.  Here a lane holds four QUERIES of one key: four quads.
+                        // The four lanes of a DPP quad hold keys 4m .. 4m + 3, so they need the same four quads: lane c hashes
+                        // the one of query ib + (c & 3) and the others come over DPP (quad_perm broadcast): one hash
+                        // (3 quarter-rate multiplies) per lane and step instead of four.
+                        uint32_t w0, w1;
+                        bpm_hash64((((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + (c & 3))) * (uint32_t)P.S + (uint32_t)j) >> 2, drop.key, w0, w1);
+                        const bool hi_word = (j & 2) != 0, hi_half = (j & 1) != 0;
+                        auto from = [&](auto R) {
+                            constexpr int r = decltype(R)::value;
+                            const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x55 * r, 0xf, 0xf, false);
+                            const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x55 * r, 0xf, 0xf, false);
+                            const uint32_t w = hi_word ? a1 : a0;
+                            const uint32_t bits = hi_half ? (w >> 16) : (w & 0xFFFFu);
+                            dm4[r] = bits < drop.thresh ? 0.0f : drop.inv_keep;
+                        };
+                        from(std::integral_constant<int, 0>{}); from(std::integral_constant<int, 1>{});
+                        from(std::integral_constant<int, 2>{}); from(std::integral_constant<int, 3>{});
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dm4[r] = bpm_drop_mult(drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
+                        for (int r = 0; r < 4; ++r)
+                            dm4[r] = bpm_drop_mult(drop, ((uint32_t)bh * (uint32_t)P.T + (uint32_t)(ib + r)) * (uint32_t)P.S + (uint32_t)j);
+                    }
                 }
                 pd[uu] = p4 * dm4;
                 ds[uu] = p4 * (dp * dm4 - d4);
