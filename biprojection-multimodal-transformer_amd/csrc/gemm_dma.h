@@ -34,6 +34,9 @@
 #ifndef BPM_EPI_AHEAD
 #define BPM_EPI_AHEAD 1       // 16-row epilogue steps whose side operands are in flight ahead of their use (8-wave configurations)
 #endif
+#ifndef BPM_DMA_EARLY
+#define BPM_DMA_EARLY 1       // see the k loop
+#endif
 #ifndef BPM_DMA_ABLATE
 #define BPM_DMA_ABLATE 0      // lab builds only (tools/gemm_lab.py): 1 no MFMA, 2 no DMA in the loop, 4 no epilogue
 #endif
@@ -333,12 +336,19 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
                         if (b / XB == wn) xs[b % XB] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fx[b], xs[b % XB], 0, 0, 0);
                 }
             }
-            if (more && !(BPM_DMA_ABLATE & 2)) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks>{});
+            // 1: the 16-wave configuration and the weight-gradient product request the whole next stage right behind the
+            // barrier (4 / 8 DMAs per wave) instead of a quarter of it between MFMA groups
+            constexpr bool EARLY = BPM_DMA_EARLY != 0 && (NW == 16 || (!XK && !YK));
+            if (more && !(BPM_DMA_ABLATE & 2)) {
+                if constexpr (EARLY) {
+                    if (ks == 0) stage(kt + NS - 1, nbuf);
+                } else part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks>{});
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < TMW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
-            if (more && !(BPM_DMA_ABLATE & 2)) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks + 1>{});
+            if (more && !(BPM_DMA_ABLATE & 2) && !EARLY) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks + 1>{});
 #pragma unroll
             for (int a = 2; a < 4; ++a)
 #pragma unroll
