@@ -71,6 +71,27 @@ def main():
             cur_e = max(cur_e, e)
     busy += cur_e - cur_s
     print(f"union busy {1e-6 * busy:.3f} ms, idle {1e-6 * (t1 - t0 - busy):.3f} ms")
+    # where nothing runs: gaps of the union timeline, largest first, with the kernels either side; and the low-occupancy
+    # stretches (only kernels shorter than 30 us running)
+    ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in step))
+    gaps, cur_e, last = [], ev[0][1], ev[0][2]
+    for st, en, k in ev[1:]:
+        if st > cur_e:
+            gaps.append((st - cur_e, 1e-6 * (cur_e - t0), last, k))
+        if en > cur_e:
+            cur_e, last = en, k
+    hist = defaultdict(lambda: [0, 0])
+    for g, _, a_, b_ in gaps:
+        hist[(a_, b_)][0] += g
+        hist[(a_, b_)][1] += 1
+    print(f"{len(gaps)} gaps; by (kernel before -> kernel after), total us:")
+    for (a_, b_), (g, n) in sorted(hist.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"   {a_:28s} -> {b_:28s} {n:4d} x {1e-3 * g / n:7.1f} us = {1e-3 * g:8.1f} us")
+    print("largest single gaps (us, at ms into the step):")
+    for g, at, a_, b_ in sorted(gaps, reverse=True)[:8]:
+        print(f"   {1e-3 * g:8.1f} us at {at:7.3f} ms   {a_} -> {b_}")
+    small = sum(en - st for st, en, k in ev if en - st < 30000)
+    print(f"kernels shorter than 30 us: {sum(1 for st, en, k in ev if en - st < 30000)} launches, {1e-6 * small:.3f} ms of queue time")
 
 
 if __name__ == "__main__":
