@@ -40,36 +40,16 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int KT = 64;      // keys per tile (forward / dQ)
-#ifndef BPM_ATTN_W128
-#define BPM_ATTN_W128 2    // waves per SIMD at head_dim 128 (unified 256-register budget: no AGPR copies)
-#endif
-#ifndef BPM_ATTN_WF
-#define BPM_ATTN_WF 5      // waves per SIMD of the forward kernel at head_dim <= 32 (90 VGPRs; dQ / dKdV spill at 5)
-#endif
-#ifndef BPM_BASE_PRIO
-#define BPM_BASE_PRIO 1      // see gemm.hip
-#endif
-#ifndef BPM_ATTN_SETPRIO
-#define BPM_ATTN_SETPRIO 1
-#endif
-#ifndef BPM_ATTN_QT
-#define BPM_ATTN_QT 64
-#endif
-#ifndef BPM_ATTN_DKV_W32
-#define BPM_ATTN_DKV_W32 4
-#endif
-#ifndef BPM_ATTN_DKV_W64
-#define BPM_ATTN_DKV_W64 3
-#endif
-#ifndef BPM_ATTN_DQ_W32
-#define BPM_ATTN_DQ_W32 5
-#endif
-#ifndef BPM_ATTN_DQ_W128
-#define BPM_ATTN_DQ_W128 3
-#endif
-#ifndef BPM_ATTN_DQ_W64
-#define BPM_ATTN_DQ_W64 4
-#endif
+constexpr int BPM_ATTN_W128 = 2;    // waves per SIMD at head_dim 128 (unified 256-register budget: no AGPR copies)
+constexpr int BPM_ATTN_WF = 5;      // waves per SIMD of the forward kernel at head_dim <= 32 (90 VGPRs; dQ / dKdV spill at 5)
+constexpr int BPM_BASE_PRIO = 1;      // see gemm.hip
+constexpr int BPM_ATTN_SETPRIO = 1;
+constexpr int BPM_ATTN_QT = 64;
+constexpr int BPM_ATTN_DKV_W32 = 4;
+constexpr int BPM_ATTN_DKV_W64 = 3;
+constexpr int BPM_ATTN_DQ_W32 = 5;
+constexpr int BPM_ATTN_DQ_W128 = 3;
+constexpr int BPM_ATTN_DQ_W64 = 4;
 constexpr int QT = BPM_ATTN_QT;      // queries per tile (dK/dV): a multiple of 32
 
 // Waves per SIMD each kernel is compiled for (register budget 512 / waves), per kernel (0 forward, 1 dQ, 2 dK/dV),
@@ -333,9 +313,7 @@ BPM_DEV void attn_fwd_block(const AProb& P, const DropCfg& drop, char* smem, con
 #pragma unroll
         for (int n = 0; n < C::ND; ++n) o[n] *= alpha;
         // O^T += V^T Pd^T : k = keys of this tile
-#if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
-#endif
+        if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
 #pragma unroll
         for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
             const frag pf = Tr<CT>::pack_rows(st, ks);
@@ -343,9 +321,7 @@ BPM_DEV void attn_fwd_block(const AProb& P, const DropCfg& drop, char* smem, con
             for (int n = 0; n < C::ND; ++n)
                 o[n] = Tr<CT>::mma(Tr<CT>::read_tr(vimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, o[n]);
         }
-#if BPM_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
-#endif
+        if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     }
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
@@ -488,16 +464,12 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, const DropCfg& drop, char* smem, 
                 ds[nn] = p4 * (dp * dm4 - delta);
             }
             // dQ^T += K^T dS^T
-#if BPM_ATTN_SETPRIO
-            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
-#endif
+            if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
             const frag df = Tr<CT>::pack_rows(ds, 0);
 #pragma unroll
             for (int n = 0; n < C::ND; ++n)
                 dq[n] = Tr<CT>::mma(Tr<CT>::read_tr(kimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dq[n]);
-#if BPM_ATTN_SETPRIO
-            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
-#endif
+            if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
         }
     }
     __syncthreads();                                   // every wave is done with the K / V images
@@ -650,9 +622,7 @@ BPM_DEV void attn_bwd_dkv_block(const AProb& P, const DropCfg& drop, char* smem,
                 pd[uu] = p4 * dm4;
                 ds[uu] = p4 * (dp * dm4 - d4);
             }
-#if BPM_ATTN_SETPRIO
-            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
-#endif
+            if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
             const frag pf = Tr<CT>::pack_rows(pd, 0);
             const frag df = Tr<CT>::pack_rows(ds, 0);
 #pragma unroll
@@ -660,9 +630,7 @@ BPM_DEV void attn_bwd_dkv_block(const AProb& P, const DropCfg& drop, char* smem,
                 dv[n] = Tr<CT>::mma(Tr<CT>::read_tr(doimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, dv[n]);
                 dk[n] = Tr<CT>::mma(Tr<CT>::read_tr(qimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), df, dk[n]);
             }
-#if BPM_ATTN_SETPRIO
-            __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
-#endif
+            if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
         }
     }
     static_assert(2 * QT * C::STRIDE >= 4 * store_rows16_bytes<CT, DHP>(), "one transpose block per wave in the Q / dO images");

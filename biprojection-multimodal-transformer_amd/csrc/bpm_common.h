@@ -195,17 +195,10 @@ BPM_DEV typename Tr<CT>::frag read_rowfrag(const char* img, int stride_b, int ro
 // Workgroups are dispatched round-robin over the 8 XCDs (workgroup i runs on XCD i % 8), each with its own L2.
 // Map the hardware workgroup id to a logical id such that every XCD works through one CONTIGUOUS eighth of the
 // logical ids: neighbouring tiles (which share operand panels) then share an L2 instead of being fetched 8 times.
-#ifndef BPM_XCD_REMAP
-#define BPM_XCD_REMAP 1
-#endif
 BPM_DEV int xcd_remap(int hw, int total) {
-#if BPM_XCD_REMAP
     const int q = total >> 3, r = total & 7;
     const int x = hw & 7;
     return x * q + min(x, r) + (hw >> 3);
-#else
-    return hw;
-#endif
 }
 
 BPM_DEV float wave_sum(float v) {

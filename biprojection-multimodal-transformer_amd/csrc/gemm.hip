@@ -43,13 +43,7 @@
 
 namespace {
 
-#ifndef BPM_BM
-#define BPM_BM 128
-#define BPM_BN 64
-#define BPM_WM 2
-#define BPM_WN 2
-#endif
-constexpr int BM = BPM_BM, BN = BPM_BN, WM = BPM_WM, WN = BPM_WN;
+constexpr int BM = 128, BN = 64, WM = 2, WN = 2;   // tiled kernel: 128 x 64 workgroup tile, 2 x 2 waves
 constexpr int NTHREADS = 64 * WM * WN;
 constexpr int TM = BM / WM / 16;          // 4 MFMA tiles along m per wave
 constexpr int TN = BN / WN / 16;          // 2 along n
@@ -59,32 +53,16 @@ constexpr int TN = BN / WN / 16;          // 2 along n
 // waves per SIMD the tiled kernel is compiled for (register budget 512 / BPM_TILED_MINW per lane): 5 fits without
 // spilling since the epilogue no longer keeps a per-row offset table (84-88 VGPRs); 6 spills and runs 1.3-1.8x slower.
 // Measured: 4 and 5 perform the same (the kernel is not occupancy-bound), so the extra wave is free headroom.
-#ifndef BPM_TILED_MINW
-#define BPM_TILED_MINW 5
-#endif
+constexpr int BPM_TILED_MINW = 5;
 // s_setprio(1) around the MFMA cluster: alone the GEMMs gain 1-10 % (wgrad 85 -> 80 us), inside the training step they
 // then take issue slots from the critical-path kernels of the other stream and the step gets SLOWER (17.0 -> 17.4 ms)
-#ifndef BPM_SETPRIO
-#define BPM_SETPRIO 0
-#endif
+constexpr int BPM_SETPRIO = 0;
 // issue priority of critical-path kernels (forward / dgrad GEMMs not flagged BACKGROUND, attention, LayerNorm) over
 // the side stream's: 16.92 -> 16.63 ms/step
-#ifndef BPM_BASE_PRIO
-#define BPM_BASE_PRIO 1
-#endif
-#ifndef BPM_DEEP_TN
-#define BPM_DEEP_TN 2
-#endif
-#ifndef BPM_DEEP_FWD
-#define BPM_DEEP_FWD 1
-#endif
-#ifndef BPM_KS_FWD
-#define BPM_KS_FWD 1
-#endif
-#ifndef BPM_KS_WGRAD
-#define BPM_KS_WGRAD 2
-#endif
-constexpr int KS_FWD = BPM_KS_FWD, KS_WGRAD = BPM_KS_WGRAD;
+constexpr int BPM_BASE_PRIO = 1;
+constexpr int BPM_DEEP_TN = 2;
+constexpr int BPM_DEEP_FWD = 1;
+constexpr int KS_FWD = 1, KS_WGRAD = 2;
 struct Prob {                              // 168 bytes: 24 of them (+ the header) are one 4 KB kernel argument
     const char* X; const char* Y; char* C;
     int M, N, K;
@@ -594,16 +572,12 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
             }
 #pragma unroll
             for (int a = 0; a < TN; ++a) fy[a] = SY::frag(iy, wn * (BN / WN) + 16 * a, ks, lane);
-#if BPM_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
+            if (BPM_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TMT; ++b) acc[a][b] = Tr<CT>::mma(fy[a], fx[b], acc[a][b]);
-#if BPM_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
+            if (BPM_SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
     };
 

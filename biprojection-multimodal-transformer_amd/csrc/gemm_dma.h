@@ -31,12 +31,8 @@
 // overhang of a k-strided operand only reaches output columns the epilogue masks.  k-contiguous operands must keep
 // whole 128-byte stages inside their zero-padded rows (checked by the dispatcher).
 
-#ifndef BPM_EPI_AHEAD
-#define BPM_EPI_AHEAD 1       // 16-row epilogue steps whose side operands are in flight ahead of their use (8-wave configurations)
-#endif
-#ifndef BPM_DMA_EARLY
-#define BPM_DMA_EARLY 1       // see the k loop
-#endif
+constexpr int BPM_EPI_AHEAD = 1;       // 16-row epilogue steps whose side operands are in flight ahead of their use (8-wave configurations)
+constexpr int BPM_DMA_EARLY = 1;       // see the k loop
 #ifndef BPM_DMA_ABLATE
 #define BPM_DMA_ABLATE 0      // lab builds only (tools/gemm_lab.py): 1 no MFMA, 2 no DMA in the loop, 4 no epilogue
 #endif

@@ -14,9 +14,7 @@
 #include "bpm_common.h"
 #include "../../include/bpmult_hip.h"
 
-#ifndef BPM_BASE_PRIO
-#define BPM_BASE_PRIO 1      // see gemm.hip
-#endif
+constexpr int BPM_BASE_PRIO = 1;      // see gemm.hip
 
 namespace {
 
