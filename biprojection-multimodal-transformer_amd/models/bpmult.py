@@ -77,7 +77,7 @@ class TextShiftingLayer(nn.Module):
 class AudioEncoder(nn.Module):
     """Front-end of the 4-modal model (mmtr.py:93-108): Conv1d(96,96,128,stride 2) x 2 + AdaptiveAvgPool1d(200).  The
     modules below only hold the parameters under the reference's names; `encode` runs the stack on the HIP path
-    (frontend.py: window gather + grouped MFMA GEMM + pooling kernels) and returns [B, 200, 96], i.e. the reference's
+    (frontend.py: the convolutions as implicit products of the grouped MFMA GEMM over the channels-last signal + pooling kernels) and returns [B, 200, 96], i.e. the reference's
     `audio_enc(audio).transpose(1, 2)`."""
 
     def __init__(self, args=None):
