@@ -20,8 +20,13 @@ LIB_PATH = os.environ.get("BPMULT_LIB", os.path.join(_HERE, "libbpmult_hip.so"))
 SOURCES = ("gemm.hip", "attention.hip", "rowops.hip", "tail.hip", "frontend.hip", "prof.hip")
 HEADERS = ("bpm_common.h", "bpm_prof.h", "gemm_dma.h")
 ARCH = "gfx950"
-PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5}
+PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5,
+              "gemm_dma_nt": 13, "gemm_dma_nn": 14, "gemm_dma_tn": 15}      # gemm_*: the 128 x 64 kernel; gemm_dma_*: the LDS-DMA kernel
 
+ABI_VERSION = 2                   # == BPM_ABI_VERSION of include/bpmult_hip.h; lib() refuses any other library
+# -DBPM_LAB build: the same kernels plus the two process-global tuning hooks (bpm_debug_gemm_force / bpm_debug_attn_pair)
+# that tools/gemm_lab.py, tools/attn_lab.py and three kernel tests use; never loaded by the product path
+LAB_LIB_PATH = os.path.join(_HERE, "..", "build", "lab", "libbpmult_hip_lab.so")
 BPM_F32, BPM_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
@@ -35,16 +40,27 @@ GEMM_MAX_GROUP = 24
 
 def build(force: bool = False, verbose: bool = False, out: str | None = None, flags: tuple = (), objdir: str | None = None) -> str:
     """hipcc --offload-arch=gfx950: every csrc/*.hip to an object file (in parallel; only the stale ones), then one shared
-    library in-tree.  `out` / `flags` / `objdir`: variant builds for the lab tools (e.g. -DBPM_DMA_ABLATE=4)."""
+    library in-tree.  `out` / `flags` / `objdir`: variant builds for the lab tools (e.g. -DBPM_DMA_ABLATE=4).  Safe when
+    several ranks call it at once: one builder at a time per object directory (file lock), objects and the library are
+    written under a temporary name and renamed into place."""
+    import fcntl
+    import hashlib
     from concurrent.futures import ThreadPoolExecutor
     out = out or LIB_PATH
-    objdir = objdir or os.path.join(_HERE, "..", "build", "obj" + ("_" + str(abs(hash(tuple(flags))) % 100000) if flags else ""))
+    # object directory named from a STABLE digest of the flags (str hashes are randomised per process)
+    tag = ("_" + hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]) if flags else ""
+    objdir = objdir or os.path.join(_HERE, "..", "build", "obj" + tag)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(_HERE, "..", "include", "bpmult_hip.h")]
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in srcs + hdrs):
+
+    def fresh():
+        return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in srcs + hdrs)
+
+    if not force and fresh():
         return out
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + list(flags)
 
@@ -52,19 +68,35 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, fl
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
             return obj
-        cmd = common + ["-c", src, "-o", obj]
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        cmd = common + ["-c", src, "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+        os.replace(tmp, obj)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():              # another rank built it while we waited
+                return out
+            with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+                objs = list(ex.map(compile_one, srcs))
+            tmp = f"{out}.{os.getpid()}.tmp"
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, out)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return out
+
+
+def build_lab(force: bool = False) -> str:
+    """The -DBPM_LAB variant (tuning hooks exported) for tools/ and the kernel tests that pin a tile configuration."""
+    return build(force=force, out=LAB_LIB_PATH, flags=("-DBPM_LAB",))
 
 
 class GemmProblem(C.Structure):
@@ -221,23 +253,52 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+def load(path: str) -> C.CDLL:
+    """dlopen + bind one build of the library; raises (never falls back) on a missing file, a missing symbol or another
+    ABI version (a stale build would be called with shifted arguments)."""
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The BPMulT hot path has no CPU/PyTorch fallback.")
+    L = C.CDLL(path)
+    for name, args in SIGNATURES.items():
+        fn = getattr(L, name)            # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = C.c_char_p if name == "bpm_error_string" else C.c_size_t if name == "bpm_ln_bwd_ws_bytes" else C.c_int
+    v = L.bpm_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"{path}: ABI version {v}, this package binds version {ABI_VERSION} (include/bpmult_hip.h): rebuild it")
+    return L
+
+
 def lib() -> C.CDLL:
     """The loaded library; raises (never falls back) when it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise HipLibraryError(
-                f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950). The BPMulT hot path has no CPU/PyTorch fallback.")
-        L = C.CDLL(LIB_PATH)
-        for name, args in SIGNATURES.items():
-            fn = getattr(L, name)            # AttributeError if the symbol is missing
-            fn.argtypes = args
-            fn.restype = C.c_char_p if name == "bpm_error_string" else C.c_size_t if name == "bpm_ln_bwd_ws_bytes" else C.c_int
-        if L.bpm_version() != 1:
-            raise HipLibraryError("libbpmult_hip.so ABI version mismatch")
-        _lib = L
+        _lib = load(LIB_PATH)
     return _lib
+
+
+class lab_library:
+    """Context manager for tools/ and tests: route this process's launches through the -DBPM_LAB build (which exports
+    bpm_debug_gemm_force / bpm_debug_attn_pair) and back.  Raises HipLibraryError when that build is absent."""
+
+    def __enter__(self) -> C.CDLL:
+        global _lib
+        self._prev = _lib
+        L = load(LAB_LIB_PATH)
+        L.bpm_debug_gemm_force.argtypes = [C.c_int]
+        L.bpm_debug_attn_pair.argtypes = [C.c_int]
+        _lib = L
+        return L
+
+    def __exit__(self, *exc) -> None:
+        global _lib
+        try:
+            _lib.bpm_debug_gemm_force(-1)
+            _lib.bpm_debug_attn_pair(7)
+        finally:
+            _lib = self._prev
 
 
 _prof_mask = 0

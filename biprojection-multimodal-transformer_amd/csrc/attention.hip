@@ -665,7 +665,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 }
 
 // tuning hook (tools/attn_lab.py): bit k = kernel k (0 forward, 1 dQ, 2 dK/dV) pairs blocks
+// bit k: kernel k (forward, dQ, dK/dV) takes two 64-row blocks per workgroup.  A constant in the product library; a
+// -DBPM_LAB build (tools/attn_lab.py, the block-pairing test) can switch it through bpm_debug_attn_pair.
+#ifdef BPM_LAB
 int g_attn_pair = 7;
+#else
+constexpr int g_attn_pair = 7;
+#endif
 
 int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S, uint64_t seed, int* total, int kernel) {
     if (nprob < 1 || nprob > BPM_MAX_GROUP || !probs) return BPM_ERR_ARG;
@@ -751,11 +757,13 @@ int dispatch(int which, int dhp, const AGroup& g, int total, hipStream_t s) {
 
 }  // namespace
 
+#ifdef BPM_LAB
 extern "C" int bpm_debug_attn_pair(int mask) {
     if (mask < 0 || mask > 7) return BPM_ERR_ARG;
     g_attn_pair = mask;
     return 0;
 }
+#endif
 
 extern "C" int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs, int nprob, uint64_t seed, void* stream) {
     AGroup g;

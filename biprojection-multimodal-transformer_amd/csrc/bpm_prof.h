@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 
 enum { BPM_K_GEMM_NT = 0, BPM_K_GEMM_NN, BPM_K_GEMM_TN, BPM_K_ATTN_FWD, BPM_K_ATTN_BWD_DQ, BPM_K_ATTN_BWD_DKV,
-       BPM_K_RESERVED6, BPM_K_LN_FWD, BPM_K_LN_BWD, BPM_K_ROWS_CAST, BPM_K_EMBED, BPM_K_GMU, BPM_K_PACK, BPM_K_COUNT };
+       BPM_K_RESERVED6, BPM_K_LN_FWD, BPM_K_LN_BWD, BPM_K_ROWS_CAST, BPM_K_EMBED, BPM_K_GMU, BPM_K_PACK,
+       BPM_K_GEMM_DMA_NT, BPM_K_GEMM_DMA_NN, BPM_K_GEMM_DMA_TN,      // the same products when the LDS-DMA kernel (gemm_dma.h) takes the launch
+       BPM_K_COUNT };
 
 extern unsigned g_bpm_prof_mask;
 void bpm_prof_open(int kind, hipStream_t s, double work, double bytes);

@@ -791,16 +791,24 @@ int num_cus() {
     return ncu;
 }
 
-// tuning hook (tools/gemm_lab.py): -1 = automatic choice, -2 = never the LDS-DMA kernel, 0.. = force DMA_CFGS[i] where legal
+// tile-configuration override: -1 = automatic choice, -2 = never the LDS-DMA kernel, 0.. = force DMA_CFGS[i] where legal.
+// A constant in the product library; only a -DBPM_LAB build (build/lab/libbpmult_hip_lab.so: tools/gemm_lab.py and the
+// kernel tests that pin a configuration) makes it a process-global switch behind bpm_debug_gemm_force.
+#ifdef BPM_LAB
 int g_force_dma = -1;
+#else
+constexpr int g_force_dma = -1;
+#endif
 
 }  // namespace
 
+#ifdef BPM_LAB
 extern "C" int bpm_debug_gemm_force(int cfg) {
     if (cfg < -2 || cfg >= N_DMA_CFGS) return BPM_ERR_ARG;
     g_force_dma = cfg;
     return 0;
 }
+#endif
 
 #ifdef BPM_GEMM_TRACE
 extern "C" int bpm_debug_trace(unsigned long long* out, int nblocks) {
@@ -936,7 +944,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         if (q.gate) bytes += mn * sz;
         if (q.out_kind == BPM_OUT_F32 && (q.flags & BPM_GEMM_ACCUM)) bytes += mn * 4;
     }
-    BpmProfScope prof(BPM_K_GEMM_NT + variant, s, flops, bytes);
+    BpmProfScope prof((dma >= 0 ? BPM_K_GEMM_DMA_NT : BPM_K_GEMM_NT) + variant, s, flops, bytes);
     if (dma >= 0) return launch_dma(dma, variant, g, s);
     return dtype == BPM_BF16 ? launch<bf16_t>(variant, fast, bm_tile == 64, g, s)
                              : launch<float>(variant, fast, bm_tile == 64, g, s);

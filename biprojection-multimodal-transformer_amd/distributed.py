@@ -21,8 +21,13 @@ reduced as one flattened message at the end.
   flat buffer and hands 1/world to the optimizer, whose kernel multiplies the
   gradient as it reads it (`bpm_adam_step(grad_scale)`).  Without an optimizer
   the buffer is scaled in place so that `.grad` holds the mean.
-* `compress`: "auto" (default) exchanges bf16 copies of the slices when the
-  fp32 gradient buffer is larger than AUTO_BF16_BYTES (1 GiB): a ring all-reduce
+* `compress`: "none" (the library default) exchanges the fp32 gradients, as the
+  reference's DataParallel reduction does.  Opt-in: "bf16" exchanges bf16 copies
+  of the slices (one rounding of each rank's summand; RCCL accumulates the sum
+  in bf16: the error against the fp32 sum is bounded in
+  tests/test_gradsync_gloo_cpu.py at world 8), "auto" does so when the fp32
+  gradient buffer is larger than AUTO_BF16_BYTES (1 GiB) -- what bench.py asks
+  for and states in its JSON line (`grad_exchange.compress`): a ring all-reduce
   moves 2 (w-1)/w x bytes over ONE xGMI link per GPU (~153 GB/s, SURVEY.md
   section 5), so the headline model's 2.7 GB of fp32 gradients are ~31 ms of
   ring time against a 30 ms step -- nothing to hide them behind -- while bf16
@@ -43,7 +48,7 @@ AUTO_BF16_BYTES = 1 << 30
 
 
 class GradSync:
-    def __init__(self, model, bucket_bytes: int = 128 << 20, process_group=None, optimizer=None, compress: str = "auto"):
+    def __init__(self, model, bucket_bytes: int = 128 << 20, process_group=None, optimizer=None, compress: str = "none"):
         if compress not in ("auto", "none", "bf16"):
             raise ValueError("compress must be 'auto', 'none' or 'bf16'")
         self.model, self.pg = model, process_group

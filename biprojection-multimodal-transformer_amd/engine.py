@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
-from ._lib import (BPM_BF16, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
+from ._lib import (BPM_BF16, AddnProblem, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
                    AttnProblem, CastProblem, FoldDesc, GemmProblem, LnProblem, PackDesc,
                    UnfoldDesc)
 from .ops import pad32
@@ -312,6 +312,11 @@ class EncoderDesc:
     q_pos0: int = 0
     q_stride: int = 1
     T_full: Optional[int] = None
+    # biprojection encoders only: the consumer reads rows {0, T-1} of the output, and under the causal
+    # self-attention a row never sees a later one, so the LAST layer's query side (self-attention queries, cross
+    # attention, FFN) and the final LayerNorm run on those two rows; its self-attention keys / values and every
+    # earlier layer stay dense.  The output is then [2, B, d].
+    tail_rows: bool = False
 
 
 @dataclass
@@ -391,11 +396,18 @@ class EncoderGroupPlan:
 
         for e in self.encs:
             R, Rk = e.T * B, e.S * B
-            b = dict(R=R, Rk=Rk)
-            b["x"] = [z(R, d) for _ in range(L + 1)]
+            tailp = bool(e.tail_rows)
+            if tailp and (not cfg.biprojection or e.T < 2 or e.T_full is not None):
+                raise ValueError("tail_rows: biprojection encoders with at least two query rows (crossmodal encoders gather their rows)")
+            # query-side rows / time steps of every layer (the last one shrinks to rows {0, T-1} with tail_rows)
+            Rl, Tl = [R] * L, [e.T] * L
+            if tailp:
+                Rl[-1], Tl[-1] = 2 * B, 2
+            b = dict(R=R, Rk=Rk, Rl=Rl, Tl=Tl, tailp=tailp)
+            b["x"] = [z(R, d) for _ in range(L)] + [z(Rl[-1], d)]
             b["ke"], b["ve"] = z(Rk, d), z(Rk, d)
-            b["out"] = z(e.T, B, d)
-            b["stf"] = (z(R), z(R))
+            b["out"] = z(Tl[-1], B, d)
+            b["stf"] = (z(Rl[-1]), z(Rl[-1]))
             # key / value source, normalised ONCE without affine (the per-layer LayerNorm gain and bias are folded
             # into the K / V projection weights, see register_encoder_shadows)
             b["khat"], b["vhat"] = z(Rk, self.ld, dt=ct), z(Rk, self.ld, dt=ct)
@@ -407,19 +419,28 @@ class EncoderGroupPlan:
             b["dkall"], b["dvall"] = z(Rk, L * self.ld, dt=ct), z(Rk, L * self.ld, dt=ct)
             b["dWf"] = [z(2 * d, d) for _ in range(L)]              # folded K/V weight gradients (per backward)
             b["dbf"] = carve(L, 2 * d)                              # folded K/V bias gradients (column sums)
-            for nm, shape, dt in (("xn", (R, self.ld), ct),
-                                  ("qh", (B, H, e.T, self.dhp), ct), ("kh", (B, H, e.S, self.dhp), ct),
-                                  ("vh", (B, H, e.S, self.dhp), ct), ("ao", (R, self.ld), ct), ("lse", (B, H, e.T), torch.float32),
-                                  ("xmid", (R, d), torch.float32), ("xn2", (R, self.ld), ct), ("h1", (R, self.ld4), ct),
-                                  ("st0m", (R,), torch.float32), ("st0r", (R,), torch.float32),
-                                  ("st1m", (R,), torch.float32), ("st1r", (R,), torch.float32)):
-                b[nm] = [z(*shape, dt=dt) for _ in range(L)]
+            # per-layer activations: shape(i) -- query-side tensors follow Rl / Tl, key / value-side ones stay full
+            for nm, shape, dt in (("xn", lambda i: (R, self.ld), ct),
+                                  ("qh", lambda i: (B, H, Tl[i], self.dhp), ct), ("kh", lambda i: (B, H, e.S, self.dhp), ct),
+                                  ("vh", lambda i: (B, H, e.S, self.dhp), ct), ("ao", lambda i: (Rl[i], self.ld), ct),
+                                  ("lse", lambda i: (B, H, Tl[i]), torch.float32),
+                                  ("xmid", lambda i: (Rl[i], d), torch.float32), ("xn2", lambda i: (Rl[i], self.ld), ct),
+                                  ("h1", lambda i: (Rl[i], self.ld4), ct),
+                                  ("st0m", lambda i: (R,), torch.float32), ("st0r", lambda i: (R,), torch.float32),
+                                  ("st1m", lambda i: (Rl[i],), torch.float32), ("st1r", lambda i: (Rl[i],), torch.float32)):
+                b[nm] = [z(*shape(i), dt=dt) for i in range(L)]
             if cfg.biprojection:
-                for nm, shape, dt in (("qs", (B, H, e.T, self.dhp), ct), ("ks", (B, H, e.T, self.dhp), ct),
-                                      ("vs", (B, H, e.T, self.dhp), ct), ("aos", (R, self.ld), ct),
-                                      ("lses", (B, H, e.T), torch.float32), ("xmid0", (R, d), torch.float32),
-                                      ("xq", (R, self.ld), ct), ("st2m", (R,), torch.float32), ("st2r", (R,), torch.float32)):
-                    b[nm] = [z(*shape, dt=dt) for _ in range(L)]
+                for nm, shape, dt in (("qs", lambda i: (B, H, Tl[i], self.dhp), ct), ("ks", lambda i: (B, H, e.T, self.dhp), ct),
+                                      ("vs", lambda i: (B, H, e.T, self.dhp), ct), ("aos", lambda i: (Rl[i], self.ld), ct),
+                                      ("lses", lambda i: (B, H, Tl[i]), torch.float32), ("xmid0", lambda i: (Rl[i], d), torch.float32),
+                                      ("xq", lambda i: (Rl[i], self.ld), ct), ("st2m", lambda i: (Rl[i],), torch.float32),
+                                      ("st2r", lambda i: (Rl[i],), torch.float32)):
+                    b[nm] = [z(*shape(i), dt=dt) for i in range(L)]
+            if tailp:
+                # last layer: rows {0, T-1} of its input (fp32) and of LN0(input) (CT), their gradients, and the residual
+                # gradient scattered back into an otherwise-zero [R, d] buffer (only the two row blocks are ever written)
+                b["xg"], b["xng"] = z(2 * B, d), z(2 * B, self.ld, dt=ct)
+                b["dxg"], b["dxng"], b["dxs"] = z(2 * B, d), z(2 * B, d), z(R, d)
             # backward temporaries (shared by all layers)
             b["dx"], b["dxn"] = z(R, d), z(R, d)
             # Off-critical-path work (weight gradients, the key/value-side dgrad + LayerNorm backward) runs on a
@@ -507,9 +528,12 @@ class EncoderGroupPlan:
         for i in range(c.layers):
             ln, qkv, att, outp, ln2, fc1, fc2 = [], [], [], [], [], [], []
             kvp = []
-            pre = dict(ln=[], qkv=[], att=[], outp=[], cast=[])      # biprojection self-attention half
+            pre = dict(ln=[], gather=[], qkv=[], att=[], outp=[], cast=[])      # biprojection self-attention half
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
+                Rq, Tq = b["Rl"][i], b["Tl"][i]                        # query-side rows / time steps of this layer
+                tail = b["tailp"] and i == c.layers - 1                # rows {0, T-1} only (EncoderDesc.tail_rows)
+                qpos = dict(q_pos0=0, q_stride=e.T - 1) if tail else dict(q_pos0=e.q_pos0, q_stride=e.q_stride)
                 P = lambda leaf: st.p(self._pn(e, i, leaf))
                 ipw = self._pn(e, i, "self_attn.in_proj_weight")
                 ipb = P("self_attn.in_proj_bias")
@@ -532,15 +556,24 @@ class EncoderGroupPlan:
                 if c.biprojection:
                     g2, b2 = P("layer_norms.2.weight"), P("layer_norms.2.bias")
                     pre["ln"].append(ops.ln_problem(x_in, g0, b0, b["st0m"][i], b["st0r"][i], R, out=b["xn"][i], ldo=ld))
-                    for w, dst in ((0, b["qs"][i]), (1, b["ks"][i]), (2, b["vs"][i])):
-                        pre["qkv"].append(proj(b["xn"][i], R, w, dst, e.T))
+                    xq_in, res_in = b["xn"][i], x_in                   # self-attention query operand, its residual
+                    if tail:
+                        # time steps 0 and T-1 are the first and the last B rows of a [T, B, .] tensor: two block copies
+                        for j, r0 in ((0, 0), (1, R - B)):
+                            pre["gather"].append(ops.cast_problem(x_in[r0:r0 + B], d, B, d, dst_f32=b["xg"][j * B:(j + 1) * B], ldf=d))
+                            pre["gather"].append(ops.cast_problem(b["xn"][i][r0:r0 + B], ld, B, d, a_is_ct=True,
+                                                                  dst_ct=b["xng"][j * B:(j + 1) * B], ldd=ld))
+                        xq_in, res_in = b["xng"], b["xg"]
+                    pre["qkv"] += [proj(xq_in, Rq, 0, b["qs"][i], Tq), proj(b["xn"][i], R, 1, b["ks"][i], e.T),
+                                   proj(b["xn"][i], R, 2, b["vs"][i], e.T)]
                     pre["att"].append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H,
-                                                       e.T, e.T, dh, dhp, self._mask_off(e.T, e.T),
-                                                       drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
-                    pre["outp"].append(ops.gemm_problem(b["aos"][i], st.sptr(wo), b["xmid0"][i], R, d, d, ld, ld, d,
-                                                        bias_n=P("self_attn.out_proj.bias"), resid=x_in, ldr=d,
+                                                       Tq, e.T, dh, dhp, self._mask_off(e.T, e.T),
+                                                       drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF),
+                                                       **(qpos if tail else {})))
+                    pre["outp"].append(ops.gemm_problem(b["aos"][i], st.sptr(wo), b["xmid0"][i], Rq, d, d, ld, ld, d,
+                                                        bias_n=P("self_attn.out_proj.bias"), resid=res_in, ldr=d,
                                                         drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
-                    pre["cast"].append(ops.cast_problem(b["xmid0"][i], d, R, d, dst_ct=b["xq"][i], ldd=ld))
+                    pre["cast"].append(ops.cast_problem(b["xmid0"][i], d, Rq, d, dst_ct=b["xq"][i], ldd=ld))
                     q_src, resid_src = b["xq"][i], b["xmid0"][i]
                     gf, bf = g2, b2
                     stf = (b["st2m"][i], b["st2r"][i])
@@ -549,25 +582,26 @@ class EncoderGroupPlan:
                     q_src, resid_src = b["xn"][i], x_in
                     gf, bf = g1, b1
                     stf = (b["st1m"][i], b["st1r"][i])
-                qkv.append(proj(q_src, R, 0, b["qh"][i], e.T))
+                qkv.append(proj(q_src, Rq, 0, b["qh"][i], Tq))
                 kvp.append(proj_kv(b["khat"], 1, b["kh"][i]))
                 kvp.append(proj_kv(b["vhat"], 2, b["vh"][i]))
-                att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
+                att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, Tq, e.S, dh, dhp,
                                             self._mask_off(e.T_full or e.T, e.S), drop_p=pr(e.attn_dropout),
-                                            drop_site=site(e.enc_id, i, S_ATTN), q_pos0=e.q_pos0, q_stride=e.q_stride))
-                outp.append(ops.gemm_problem(b["ao"][i], st.sptr(wo), b["xmid"][i], R, d, d, ld, ld, d,
+                                            drop_site=site(e.enc_id, i, S_ATTN), **qpos))
+                outp.append(ops.gemm_problem(b["ao"][i], st.sptr(wo), b["xmid"][i], Rq, d, d, ld, ld, d,
                                              bias_n=P("self_attn.out_proj.bias"), resid=resid_src, ldr=d,
                                              drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES1)))
-                ln2.append(ops.ln_problem(b["xmid"][i], gf, bf, stf[0], stf[1], R, out=b["xn2"][i], ldo=ld))
-                fc1.append(ops.gemm_problem(b["xn2"][i], st.sptr(w1), b["h1"][i], R, 4 * d, d, ld, ld, ld4, bias_n=P("fc1.bias"),
+                ln2.append(ops.ln_problem(b["xmid"][i], gf, bf, stf[0], stf[1], Rq, out=b["xn2"][i], ldo=ld))
+                fc1.append(ops.gemm_problem(b["xn2"][i], st.sptr(w1), b["h1"][i], Rq, 4 * d, d, ld, ld, ld4, bias_n=P("fc1.bias"),
                                             flags=F_RELU, drop_p=pr(c.relu_dropout), drop_site=site(e.enc_id, i, S_RELU),
                                             out_kind=OUT_CT))
-                fc2.append(ops.gemm_problem(b["h1"][i], st.sptr(w2), b["x"][i + 1], R, d, 4 * d, ld4, ld4, d, bias_n=P("fc2.bias"),
+                fc2.append(ops.gemm_problem(b["h1"][i], st.sptr(w2), b["x"][i + 1], Rq, d, 4 * d, ld4, ld4, d, bias_n=P("fc2.bias"),
                                             resid=b["xmid"][i], ldr=d, drop_p=pr(c.res_dropout),
                                             drop_site=site(e.enc_id, i, S_RES2)))
             if c.biprojection:
-                steps += [(ops.ln_fwd, self.dtype, A(LnProblem, pre["ln"]), d),
-                          self._gemm(GEMM_NT, pre["qkv"]),
+                steps += [(ops.ln_fwd, self.dtype, A(LnProblem, pre["ln"]), d)] + \
+                         ([(ops.rows_cast, self.dtype, A(CastProblem, pre["gather"]))] if pre["gather"] else []) + \
+                         [self._gemm(GEMM_NT, pre["qkv"]),
                           (ops.attn_fwd, self.dtype, A(AttnProblem, pre["att"])),
                           self._gemm(GEMM_NT, pre["outp"]),
                           (ops.rows_cast, self.dtype, A(CastProblem, pre["cast"]))]
@@ -584,7 +618,7 @@ class EncoderGroupPlan:
                       self._gemm(GEMM_NT, fc1),
                       self._gemm(GEMM_NT, fc2)]
         fin = [ops.ln_problem(b["x"][c.layers], st.p(e.prefix + "layer_norm.weight"), st.p(e.prefix + "layer_norm.bias"),
-                              b["stf"][0], b["stf"][1], b["R"], out=b["out"], ldo=d, out_f32=True)
+                              b["stf"][0], b["stf"][1], b["Rl"][-1], out=b["out"], ldo=d, out_f32=True)
                for e, b in zip(self.encs, self.buf)]
         steps.append((ops.ln_fwd, self.dtype, A(LnProblem, fin), d))
         return kv_steps + steps + [JOIN]
@@ -601,6 +635,8 @@ class EncoderGroupPlan:
             fn(s[1], s[2], self.dtype, seed)
         elif fn is ops.unfold_grads:
             fn(s[1], s[2], s[3], s[4])
+        elif fn is ops.add_n:
+            fn(s[1])
         else:
             raise RuntimeError("unknown step")
 
@@ -699,8 +735,12 @@ class EncoderGroupPlan:
             wg_ffn, dg_fc2, dg_fc1, lnf = [], [], [], []
             wg_att, dg_out, att, dg_q, lnq = [], [], [], [], []
             s_cast0, s_dgout0, s_att0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], []
+            s_dgq, s_scatter = [], []                 # tail_rows (last layer): d(LN0 rows {0, T-1}) and the scatter back to [R, d]
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
+                Rq, Tq = b["Rl"][i], b["Tl"][i]                        # query-side rows / time steps of this layer
+                tail = b["tailp"] and i == c.layers - 1
+                qpos = dict(q_pos0=0, q_stride=e.T - 1) if tail else dict(q_pos0=e.q_pos0, q_stride=e.q_stride)
                 P = lambda leaf: st.p(self._pn(e, i, leaf))
                 GP = lambda leaf, off=0: st.gptr(self._pn(e, i, leaf), off)
                 ipw = self._pn(e, i, "self_attn.in_proj_weight")
@@ -708,7 +748,9 @@ class EncoderGroupPlan:
                 lnF = 2 if c.biprojection else 1      # FFN LayerNorm index
                 lnK = 1 if c.biprojection else 0      # key/value LayerNorm index
                 stF = (b["st2m"][i], b["st2r"][i]) if c.biprojection else (b["st1m"][i], b["st1r"][i])
-                dx = b["dx"]
+                # residual-stream gradient of this layer's query rows: the two gathered rows in a tail_rows last layer
+                # (its LayerNorm-0 backward over all rows then writes the dense dx the layers below continue from)
+                dx = b["dxg"] if tail else b["dx"]
                 par = i & 1
                 dh1, dy, dq, dao, delta = (b[n][par] for n in ("dh1", "dy", "dq", "dao", "delta"))
                 ldk = c.layers * ld                       # layer i's dK / dV: column block i of dkall / dvall
@@ -721,73 +763,91 @@ class EncoderGroupPlan:
                 if c.biprojection:
                     dy0, dqs, dks, dvs = (b[n][par] for n in ("dy0", "dqs", "dks", "dvs"))
                 # ---- FFN
-                wg_ffn.append(ops.gemm_problem(dyf, b["h1"][i], GP("fc2.weight"), d, 4 * d, R, ld, ld4, 4 * d,
+                wg_ffn.append(ops.gemm_problem(dyf, b["h1"][i], GP("fc2.weight"), d, 4 * d, Rq, ld, ld4, 4 * d,
                                                flags=ACC1))
-                dg_fc2.append(ops.gemm_problem(dyf, st.sptr(w2), dh1, R, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
+                dg_fc2.append(ops.gemm_problem(dyf, st.sptr(w2), dh1, Rq, 4 * d, d, ld, ld4, ld4, gate=b["h1"][i], ldg=ld4,
                                                gate_scale=inv_relu, colsum=GP("fc1.bias"), out_kind=OUT_CT))
-                wg_ffn.append(ops.gemm_problem(dh1, b["xn2"][i], GP("fc1.weight"), 4 * d, d, R, ld4, ld, d,
+                wg_ffn.append(ops.gemm_problem(dh1, b["xn2"][i], GP("fc1.weight"), 4 * d, d, Rq, ld4, ld, d,
                                                flags=ACC1))
-                dg_fc1.append(ops.gemm_problem(dh1, st.sptr(w1), b["dxn"], R, d, 4 * d, ld4, ld, d))
-                lnf.append(ops.ln_problem(b["xmid"][i], P(f"layer_norms.{lnF}.weight"), None, stF[0], stF[1], R, dy=b["dxn"], ldy=d,
+                dg_fc1.append(ops.gemm_problem(dh1, st.sptr(w1), b["dxn"], Rq, d, 4 * d, ld4, ld, d))
+                lnf.append(ops.ln_problem(b["xmid"][i], P(f"layer_norms.{lnF}.weight"), None, stF[0], stF[1], Rq, dy=b["dxn"], ldy=d,
                                           add=dx, dx=dx, dgamma=GP(f"layer_norms.{lnF}.weight"), dbeta=GP(f"layer_norms.{lnF}.bias"),
                                           cast=dy, ldc=ld, cast_colsum=GP("self_attn.out_proj.bias"), drop_p=pr(c.res_dropout),
                                           drop_site=site(e.enc_id, i, S_RES1)))
                 # ---- (cross) attention block
                 # (cross-attention half: the first writer of out_proj.weight / in_proj_weight rows [0, d) on the side stream; the
                 # biprojection self-attention half below comes second and accumulates)
-                wg_att.append(ops.gemm_problem(dy, b["ao"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
+                wg_att.append(ops.gemm_problem(dy, b["ao"][i], GP("self_attn.out_proj.weight"), d, d, Rq, ld, ld, d,
                                                flags=ACC1))
-                dg_out.append(ops.gemm_problem(dy, st.sptr(wo), dao, R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
-                                               heads=(B, H, e.T, dh, dhp)))
-                att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, e.T, e.S, dh, dhp,
+                dg_out.append(ops.gemm_problem(dy, st.sptr(wo), dao, Rq, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                                               heads=(B, H, Tq, dh, dhp)))
+                att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, Tq, e.S, dh, dhp,
                                             self._mask_off(e.T_full or e.T, e.S), dO=dao, delta=delta, dQ=dq, lddq=ld,
                                             dK=dk, lddk=ldk, dV=dv, lddv=ldk, dq_scale=self.scale,
-                                            drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN),
-                                            q_pos0=e.q_pos0, q_stride=e.q_stride))
+                                            drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN), **qpos))
                 ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
                 # query projection: gradients go straight to the parameters.  Key / value projections ran with the
                 # LayerNorm folded in: their bias column sums and weight gradients (against khat / vhat) land in
                 # per-layer scratch and are unfolded into in_proj / LayerNorm gradients by one launch at the end.
                 # (the bias column sums ride on the weight-gradient GEMMs: colsum_a, one extra MFMA against ones)
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
-                wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, R, ld, ld, d, flags=ACC1,
+                wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, Rq, ld, ld, d, flags=ACC1,
                                                colsum_a=st.gptr(ipb_g, 0)))
                 wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][:d]))
                 wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][d:]))
                 if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
-                    dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), dx, R, d, d, ld, ld, d, flags=F_ACCUM))
+                    dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), dx, Rq, d, d, ld, ld, d, flags=F_ACCUM))
                 else:
-                    dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), b["dxn"], R, d, d, ld, ld, d))
-                    lnq.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R, dy=b["dxn"],
+                    dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), b["dxn"], Rq, d, d, ld, ld, d))
+                    lnq.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], Rq, dy=b["dxn"],
                                               ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias"),
                                               **nxt))
                 if c.biprojection:
                     # ---- self-attention half (same attention parameters)
-                    s_cast0.append(ops.cast_problem(dx, d, R, d, dst_ct=dy0, ldd=ld, colsum=GP("self_attn.out_proj.bias"),
+                    s_cast0.append(ops.cast_problem(dx, d, Rq, d, dst_ct=dy0, ldd=ld, colsum=GP("self_attn.out_proj.bias"),
                                                     drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i, S_RES0)))
-                    s_wg0.append(ops.gemm_problem(dy0, b["aos"][i], GP("self_attn.out_proj.weight"), d, d, R, ld, ld, d,
+                    s_wg0.append(ops.gemm_problem(dy0, b["aos"][i], GP("self_attn.out_proj.weight"), d, d, Rq, ld, ld, d,
                                                   flags=F_ACCUM))
-                    s_dgout0.append(ops.gemm_problem(dy0, st.sptr(wo), b["dao0"], R, d, d, ld, ld, 0, out_kind=OUT_HEADS,
-                                                     heads=(B, H, e.T, dh, dhp)))
-                    s_att0.append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H, e.T, e.T,
+                    s_dgout0.append(ops.gemm_problem(dy0, st.sptr(wo), b["dao0"], Rq, d, d, ld, ld, 0, out_kind=OUT_HEADS,
+                                                     heads=(B, H, Tq, dh, dhp)))
+                    s_att0.append(ops.attn_problem(b["qs"][i], b["ks"][i], b["vs"][i], b["aos"][i], ld, b["lses"][i], B, H, Tq, e.T,
                                                    dh, dhp, self._mask_off(e.T, e.T), dO=b["dao0"], delta=b["delta0"], dQ=dqs,
                                                    lddq=3 * ld, dK=dks, lddk=3 * ld, dV=dvs, lddv=3 * ld, dq_scale=self.scale,
-                                                   drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF)))
+                                                   drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN_SELF),
+                                                   **(qpos if tail else {})))
                     # in_proj_weight rows [d, 3d): this launch is their first writer (unfold_grads comes after it and adds)
-                    for w, src in ((0, dqs), (1, dks), (2, dvs)):
-                        s_wg0.append(ops.gemm_problem(src, b["xn"][i], st.gptr(ipw, w * d * d), d, d, R, 3 * ld, ld, d,
+                    xq_in = b["xng"] if tail else b["xn"][i]
+                    for w, src, xin, rows in ((0, dqs, xq_in, Rq), (1, dks, b["xn"][i], R), (2, dvs, b["xn"][i], R)):
+                        s_wg0.append(ops.gemm_problem(src, xin, st.gptr(ipw, w * d * d), d, d, rows, 3 * ld, ld, d,
                                                       flags=F_ACCUM if w == 0 else ACC1, colsum_a=st.gptr(ipb_g, w * d)))
                     # d(xn) = dq Wq + dk Wk + dv Wv: three launches (plain store, then two +=) -- one owner per
                     # output tile in each launch, no atomics (per-lane-scattered float atomics run ~17x below store rate)
-                    if ld == d:                                   # one product over K = 3d (see the dqkvs buffer)
+                    if tail:
+                        # keys / values come from every row, the query only from rows {0, T-1}: d(xn) over all rows is the
+                        # K / V part; the query part is a [2B, d] product whose row blocks are added into it, and the
+                        # gathered rows' residual gradient goes to the same two row blocks of the otherwise-zero dxs
+                        if ld == d:
+                            s_dg0a.append(ops.gemm_problem(b["dqkvs"][par][:R, ld:], st.sptr(ipw, d * ld), b["dxn"], R, d, 2 * d,
+                                                           3 * ld, ld, d))
+                        else:
+                            s_dg0a.append(ops.gemm_problem(dks, st.sptr(ipw, d * ld), b["dxn"], R, d, d, 3 * ld, ld, d))
+                            s_dg0b.append(ops.gemm_problem(dvs, st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, 3 * ld, ld, d, flags=F_ACCUM))
+                        s_dgq.append(ops.gemm_problem(dqs, st.sptr(ipw, 0), b["dxng"], Rq, d, d, 3 * ld, ld, d))
+                        for j, r0 in ((0, 0), (1, R - B)):
+                            blk = slice(j * B, (j + 1) * B)
+                            s_scatter.append(ops.addn_problem(b["dxn"][r0:r0 + B], [b["dxn"][r0:r0 + B], b["dxng"][blk]]))
+                            s_scatter.append(ops.addn_problem(b["dxs"][r0:r0 + B], [b["dxg"][blk]]))
+                    elif ld == d:                                   # one product over K = 3d (see the dqkvs buffer)
                         s_dg0a.append(ops.gemm_problem(b["dqkvs"][par], st.sptr(ipw, 0), b["dxn"], R, d, 3 * d, 3 * ld, ld, d))
                     else:
                         s_dg0a.append(ops.gemm_problem(dqs, st.sptr(ipw, 0), b["dxn"], R, d, d, 3 * ld, ld, d))
                         s_dg0b.append(ops.gemm_problem(dks, st.sptr(ipw, d * ld), b["dxn"], R, d, d, 3 * ld, ld, d, flags=F_ACCUM))
                         s_dg0c.append(ops.gemm_problem(dvs, st.sptr(ipw, 2 * d * ld), b["dxn"], R, d, d, 3 * ld, ld, d, flags=F_ACCUM))
                     s_ln0.append(ops.ln_problem(b["x"][i], P("layer_norms.0.weight"), None, b["st0m"][i], b["st0r"][i], R,
-                                                dy=b["dxn"], ldy=d, add=dx, dx=dx, dgamma=GP("layer_norms.0.weight"),
-                                                dbeta=GP("layer_norms.0.bias"), **nxt))
+                                                dy=b["dxn"], ldy=d, add=b["dxs"] if tail else dx, dx=b["dx"],
+                                                dgamma=GP("layer_norms.0.weight"), dbeta=GP("layer_norms.0.bias"), **nxt))
+            for group in (lnf, lnq, s_ln0):               # each LayerNorm-backward launch owns its gradient rows exactly once
+                ops.check_ln_rows(group, d)
             # Ownership of parameter-gradient words (bpm_ln_bwd_ws adds its row sums with a plain read-modify-write):
             # layer_norms.* / out_proj.bias / fc2.bias gradients are written by the MAIN stream's LayerNorm backward
             # launches only, except layer_norms.{lnK} which unfold_grads (side stream) also adds to -- that launch is
@@ -816,7 +876,8 @@ class EncoderGroupPlan:
                           (ops.attn_bwd, self.dtype, A(AttnProblem, s_att0)),
                           (SIDE, self._gemm(GEMM_TN, s_wg0, background=True)),
                           self._gemm(GEMM_NN, s_dg0a)] + \
-                         ([self._gemm(GEMM_NN, s_dg0b), self._gemm(GEMM_NN, s_dg0c)] if s_dg0b else []) + \
+                         ([self._gemm(GEMM_NN, s_dg0b)] if s_dg0b else []) + ([self._gemm(GEMM_NN, s_dg0c)] if s_dg0c else []) + \
+                         ([self._gemm(GEMM_NN, s_dgq), (ops.add_n, A(AddnProblem, s_scatter))] if s_dgq else []) + \
                          [(ops.ln_bwd, A(LnProblem, s_ln0), d)]
             # folded K/V gradients of this layer -> in_proj / LayerNorm parameter gradients; with it every gradient of
             # layer i is final once the side stream reaches MARK i and the main stream this point (all-reduce hook)
@@ -849,14 +910,17 @@ class EncoderGroupPlan:
         top = c.layers - 1
         self._acc0.zero_()
         for e, b, g in zip(self.encs, self.buf, douts):
+            dx_top = b["dxg"] if b["tailp"] else b["dx"]          # gradient of the top layer's output rows
             if g is None:
-                b["dx"].zero_()
+                dx_top.zero_()
                 b["dyf"][top % 3].zero_()
                 continue
+            if tuple(g.shape) != (b["Tl"][-1], B, d) or g.dtype != torch.float32:
+                raise ValueError(f"encoder {e.prefix}: output gradient must be fp32 [{b['Tl'][-1]},{B},{d}], got {tuple(g.shape)} {g.dtype}")
             g = g.contiguous()
             keep.append(g)
-            fin.append(ops.ln_problem(b["x"][c.layers], st.p(e.prefix + "layer_norm.weight"), None, b["stf"][0], b["stf"][1], b["R"],
-                                      dy=g, ldy=d, dx=b["dx"], dgamma=st.gptr(e.prefix + "layer_norm.weight"),
+            fin.append(ops.ln_problem(b["x"][c.layers], st.p(e.prefix + "layer_norm.weight"), None, b["stf"][0], b["stf"][1], b["Rl"][-1],
+                                      dy=g, ldy=d, dx=dx_top, dgamma=st.gptr(e.prefix + "layer_norm.weight"),
                                       dbeta=st.gptr(e.prefix + "layer_norm.bias"),
                                       cast=b["dyf"][top % 3], ldc=self.ld, cast_colsum=st.gptr(self._pn(e, top, "fc2.bias")),
                                       drop_p=c.res_dropout if training else 0.0, drop_site=site(e.enc_id, top, S_RES2)))

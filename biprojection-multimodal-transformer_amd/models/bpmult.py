@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from .. import config, ops
-from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, SEED_INDIRECT, CastProblem, GemmProblem, GmuProblem, TailDesc, TailGrads
+from .._lib import BPM_F32, F_ACCUM, GEMM_NN, GEMM_NT, GEMM_TN, CastProblem, GemmProblem, GmuProblem, TailDesc, TailGrads
 from ..engine import SITE_TEXT, EncoderDesc, EncoderGroupPlan, GroupCfg, ParamStore, register_encoder_shadows
 from ..ops import pad32
 from .encoder import TransformerEncoder
@@ -134,13 +134,21 @@ class _Trunk:
         adrop = {"l": model.attn_dropout, "a": model.attn_dropout_a, "v": model.attn_dropout_v}
         e1 = [EncoderDesc(n + ".", ENC_ORDER.index(n), self.N[q], self.N[kv], adrop[key]) for n, (q, kv, key) in LEVEL1.items()]
         # Exact dead-row elimination (verified on the reference): in a crossmodal encoder a query row
-        # never sees another query row (keys / values come from the other source in every layer), the Fusion-GMU is
-        # position-wise, and the head consumes only rows 0 and N-1 (mmtr.py:808,830,852).  So the level-2 encoders
-        # and the GMUs only need those two query rows; level 1 stays dense (it is level 2's key / value source).
-        self.prune = bool(getattr(model, "prune_unused_rows", False)) and not model.four_modal and min(self.N.values()) >= 2
-        self.Ng = {k: (2 if self.prune else n) for k, n in self.N.items()}            # rows of level-2 / GMU tensors
+        # never sees another query row (keys / values come from the other source in every layer), the Fusion-GMU and
+        # the level 1 -> 2 / 1 -> 3 residuals are position-wise, and the head consumes only rows 0 and N-1
+        # (mmtr.py:522,545,568 / 808,830,852).  3-modal model: the level-2 encoders and the GMUs only need those two
+        # query rows.  4-modal model: the level-2 encoders are biprojection encoders whose causal self-attention lets a
+        # row see the earlier rows, so only their LAST layer shrinks (its self-attention queries, cross attention, FFN
+        # and the final LayerNorm: EncoderDesc.tail_rows); the GMUs and the OUTPUTS of the time-axis maps (two rows of
+        # transfm_*, mmtr.py:507-508,530,553) follow.  Level 1 stays dense (it is level 2's key / value source).
+        self.prune = bool(getattr(model, "prune_unused_rows", False)) and min(self.N.values()) >= 2
+        self.Ng = {k: (2 if self.prune else n) for k, n in self.N.items()}            # rows of level-2 outputs / GMU tensors
         if self.prune:
             self.idx = {k: torch.tensor([0, n - 1], device=dev) for k, n in self.N.items()}
+        if self.prune and model.four_modal:
+            e2 = [EncoderDesc(n + ".", ENC_ORDER.index(n), self.N[q], self.N[LEVEL1[src][0]], adrop[key], tail_rows=True)
+                  for n, (q, src, key) in LEVEL2.items()]
+        elif self.prune:
             self.pxg = {k: z(2, B, d) for k in self.N}
             e2 = [EncoderDesc(n + ".", ENC_ORDER.index(n), 2, self.N[LEVEL1[src][0]], adrop[key], q_pos0=0,
                               q_stride=self.N[q] - 1, T_full=self.N[q]) for n, (q, src, key) in LEVEL2.items()]
@@ -151,9 +159,10 @@ class _Trunk:
         self.plan2 = EncoderGroupPlan(st, cfg2, e2, B)
         self.out1 = {n: b["out"] for n, b in zip(LEVEL1, self.plan1.buf)}
         self.out2 = {n: b["out"] for n, b in zip(LEVEL2, self.plan2.buf)}
-        self.d1buf = {n: z(self.N[q], B, d) for n, (q, _, _) in LEVEL1.items()} if not self.prune else {}   # d(level-1 outputs)
-        if self.prune:                      # rows 0 and N-1 of every level-1 output, as the GMUs see them
-            self.out1g = {n: z(2, B, d) for n in LEVEL1}
+        self.d1buf = {n: z(self.N[q], B, d) for n, (q, _, _) in LEVEL1.items()}   # d(level-1 outputs)
+        if self.prune:                      # rows 0 and N-1 of the level-1 outputs the GMUs read directly (not through a time map)
+            mapped = {src for (tgt, maps) in TIME_MAP.items() for src in maps} if model.four_modal else set()
+            self.out1g = {n: z(2, B, d) for n in LEVEL1 if n not in mapped}
         # ---- time-axis maps (4-modal only)
         self.tmap: Dict[Tuple[str, str], dict] = {}
         if model.four_modal:
@@ -162,8 +171,9 @@ class _Trunk:
             for tgt, maps in TIME_MAP.items():
                 for src_name, lin in maps.items():
                     Ts, Td = self.N[LEVEL1[src_name][0]], self.N[tgt]
-                    self.tmap[(tgt, src_name)] = dict(lin=lin, Ts=Ts, Td=Td, ldbd=ldbd, h_ct=z(Ts, ldbd, dt=ct), out=z(Td, B, d),
-                                                      dout=z(Td, B, d), dout_ct=z(Td, ldbd, dt=ct), dh=z(Ts, B, d))
+                    To = self.Ng[tgt]                      # output rows computed: all, or rows {0, Td-1}
+                    self.tmap[(tgt, src_name)] = dict(lin=lin, Ts=Ts, Td=Td, ldbd=ldbd, h_ct=z(Ts, ldbd, dt=ct), out=z(To, B, d),
+                                                      dout=z(To, B, d), dout_ct=z(To, ldbd, dt=ct), dh=z(Ts, B, d))
             self.ones_bd = torch.ones(1, ldbd, device=dev, dtype=ct)
             self.ones_bd[:, BD:] = 0
         # ---- dense Fusion-GMU layers: per target modality a "middle" and a "top" unit
@@ -263,26 +273,38 @@ class _Trunk:
         casts, gemms = [], []
         for (tgt, src), t in self.tmap.items():
             casts.append(ops.cast_problem(self.out1[src], BD, t["Ts"], BD, dst_ct=t["h_ct"], ldd=t["ldbd"]))
-            gemms.append(ops.gemm_problem(st.sptr(t["lin"] + ".weight"), t["h_ct"], t["out"], t["Td"], BD, t["Ts"], pad32(t["Ts"]),
-                                          t["ldbd"], BD, bias_m=st.p(t["lin"] + ".bias")))
+            ldw = pad32(t["Ts"])
+            if self.prune:            # output rows {0, Td-1} only: one single-row product each (the row's own bias entry)
+                for j, r in enumerate((0, t["Td"] - 1)):
+                    gemms.append(ops.gemm_problem(st.sptr(t["lin"] + ".weight", r * ldw), t["h_ct"], t["out"][j], 1, BD, t["Ts"], ldw,
+                                                  t["ldbd"], BD, bias_m=st.p(t["lin"] + ".bias").data_ptr() + 4 * r))
+            else:
+                gemms.append(ops.gemm_problem(st.sptr(t["lin"] + ".weight"), t["h_ct"], t["out"], t["Td"], BD, t["Ts"], ldw,
+                                              t["ldbd"], BD, bias_m=st.p(t["lin"] + ".bias")))
         ops.rows_cast(self.dtype, casts, 0)
         ops.gemm_grouped(self.dtype, GEMM_NN, gemms, 0)
 
     def _time_backward(self) -> None:
-        """dout (fp32 [Td,B,d]) of every map -> weight / bias gradients and dh (fp32 [Ts,B,d])."""
+        """dout (fp32 [Td,B,d], or rows {0, Td-1} of it) of every map -> weight / bias gradients and dh (fp32 [Ts,B,d])."""
         if not self.tmap:
             return
         B, d, st = self.B, self.d, self.st
         BD = B * d
         casts, wg, dg = [], [], []
         for (tgt, src), t in self.tmap.items():
-            casts.append(ops.cast_problem(t["dout"], BD, t["Td"], BD, dst_ct=t["dout_ct"], ldd=t["ldbd"]))
-            wg.append(ops.gemm_problem(t["dout_ct"], t["h_ct"], st.gptr(t["lin"] + ".weight"), t["Td"], t["Ts"], BD, t["ldbd"], t["ldbd"],
-                                       t["Ts"], flags=F_ACCUM))
-            wg.append(ops.gemm_problem(t["dout_ct"], self.ones_bd, st.gptr(t["lin"] + ".bias"), t["Td"], 1, BD, t["ldbd"], t["ldbd"], 1,
-                                       flags=F_ACCUM))
-            dg.append(ops.gemm_problem(st.sptr(t["lin"] + ".weight"), t["dout_ct"], t["dh"], t["Ts"], BD, t["Td"], pad32(t["Ts"]),
-                                       t["ldbd"], BD))
+            Ts, Td, ldbd = t["Ts"], t["Td"], t["ldbd"]
+            ldw = pad32(Ts)
+            W, bias = t["lin"] + ".weight", t["lin"] + ".bias"
+            casts.append(ops.cast_problem(t["dout"], BD, t["dout"].shape[0], BD, dst_ct=t["dout_ct"], ldd=ldbd))
+            if self.prune:            # rows {0, Td-1} of the weight / bias gradient (the other rows' are zero: cleared with the
+                for j, r in enumerate((0, Td - 1)):          # small tensors); dh = W[{0, Td-1}]^T dout: k = the two rows, Td-1 apart
+                    wg.append(ops.gemm_problem(t["dout_ct"][j], t["h_ct"], st.gptr(W, r * Ts), 1, Ts, BD, ldbd, ldbd, Ts, flags=F_ACCUM))
+                    wg.append(ops.gemm_problem(t["dout_ct"][j], self.ones_bd, st.gptr(bias, r), 1, 1, BD, ldbd, ldbd, 1, flags=F_ACCUM))
+                dg.append(ops.gemm_problem(st.sptr(W), t["dout_ct"], t["dh"], Ts, BD, 2, (Td - 1) * ldw, ldbd, BD))
+            else:
+                wg.append(ops.gemm_problem(t["dout_ct"], t["h_ct"], st.gptr(W), Td, Ts, BD, ldbd, ldbd, Ts, flags=F_ACCUM))
+                wg.append(ops.gemm_problem(t["dout_ct"], self.ones_bd, st.gptr(bias), Td, 1, BD, ldbd, ldbd, 1, flags=F_ACCUM))
+                dg.append(ops.gemm_problem(st.sptr(W), t["dout_ct"], t["dh"], Ts, BD, Td, ldw, ldbd, BD))
         ops.rows_cast(self.dtype, casts, 0)
         ops.gemm_grouped(self.dtype, GEMM_NT, wg, 0)
         ops.gemm_grouped(self.dtype, GEMM_TN, dg, 0)
@@ -357,10 +379,11 @@ class _Trunk:
         k1 = [px[kv] for (q, kv, _) in LEVEL1.values()]
         self.plan1.forward(q1, k1, k1, seed, training)
         if self.prune:
+            for n, t in self.out1g.items():
+                torch.index_select(self.out1[n], 0, self.idx[LEVEL1[n][0]], out=t)
+        if self.prune and not self.m.four_modal:
             for k in self.N:
                 torch.index_select(px[k], 0, self.idx[k], out=self.pxg[k])
-            for n, (q, _, _) in LEVEL1.items():
-                torch.index_select(self.out1[n], 0, self.idx[q], out=self.out1g[n])
             q2 = [self.pxg[q] for (q, src, _) in LEVEL2.values()]
         else:
             q2 = [px[q] for (q, src, _) in LEVEL2.values()]
@@ -470,18 +493,17 @@ class _Trunk:
         for (tgt, name), t in self.tmap.items():
             gmu_terms[name] = [t["dh"]]
         dq2, dk2, dv2 = self.plan2.backward([d2[n] for n in LEVEL2], self._layer_hook("level2"), stores=stores)
-        if self.prune:                       # the GMU terms only touch rows 0 and N-1 of the level-1 output
-            for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
-                full = gk + gv
-                for t in gmu_terms[src]:
-                    full.index_add_(0, self.idx[LEVEL1[src][0]], t.view(2, self.B, self.d))
-                d1[src] = full
-        else:
-            sums = []
-            for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
-                d1[src] = self.d1buf[src]
-                sums.append(ops.addn_problem(d1[src], gmu_terms[src] + [gk, gv]))
-            ops.add_n(sums)
+        # d(level-1 output) = its key / value gradients from level 2 + the GMU terms: whole-tensor terms (dense schedule,
+        # or through a time map) summed by one grouped launch, two-row terms (pruned schedule: rows 0 and N-1) added on top
+        sums, rows2 = [], []
+        for (n, (q, src, _)), gk, gv in zip(LEVEL2.items(), dk2, dv2):
+            d1[src] = self.d1buf[src]
+            full = [t for t in gmu_terms[src] if t.numel() == d1[src].numel()]
+            rows2 += [(src, t) for t in gmu_terms[src] if t.numel() != d1[src].numel()]
+            sums.append(ops.addn_problem(d1[src], [t.view(d1[src].shape) for t in full] + [gk, gv]))
+        ops.add_n(sums)
+        for src, t in rows2:
+            d1[src].index_add_(0, self.idx[LEVEL1[src][0]], t.view(2, self.B, self.d))
         dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1], self._layer_hook("level1"), stores=stores)
         acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
@@ -489,7 +511,7 @@ class _Trunk:
             acc[kv] += [gk, gv]
         small: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, src, _)), gq in zip(LEVEL2.items(), dq2):
-            (small if self.prune else acc)[q].append(gq)
+            (small if gq.shape[0] != self.N[q] else acc)[q].append(gq)
         ops.add_n([ops.addn_problem(self.dpx[k], terms) for k, terms in acc.items()])
         for k in acc:
             for gq in small[k]:
@@ -513,7 +535,7 @@ class _Trunk:
         if getattr(self, "_seed_dev", None) is None:
             self._seed_dev = torch.zeros(1, device=self.st.device, dtype=torch.int64)
         self._seed_dev.fill_(seed)
-        return SEED_INDIRECT | self._seed_dev.data_ptr()
+        return ops.DeviceSeed(self._seed_dev)
 
     def graph_forward(self, feats: Dict[str, torch.Tensor], extra: Optional[torch.Tensor], seed: int, training: bool, want_grad: bool):
         """Forward pass through a captured graph when one exists (or can be captured now) for this key; returns
@@ -660,9 +682,11 @@ class _BPMulTBase(nn.Module):
         self.relu_dropout, self.res_dropout = args.relu_dropout, args.res_dropout
         self.out_dropout, self.embed_dropout, self.attn_mask = args.out_dropout, args.embed_dropout, args.attn_mask
         self.precision: Optional[str] = getattr(args, "precision", None)
-        # exact dead-row elimination in level 2 + GMUs (3-modal model only; see _Trunk); off by default so that the
-        # default schedule is the reference's dense one
-        self.prune_unused_rows = bool(getattr(args, "prune_unused_rows", False)) or os.environ.get("BPMULT_PRUNE") == "1"
+        # exact dead-row elimination (see _Trunk): ON by default -- same logits, gates and gradients as the
+        # reference's dense schedule (pinned against the reference fixtures in both schedules, tests/test_model_gpu.py).
+        # `args.prune_unused_rows=False`, `set_prune_unused_rows(False)` or BPMULT_PRUNE=0 run the dense schedule.
+        flag = getattr(args, "prune_unused_rows", None)
+        self.prune_unused_rows = (os.environ.get("BPMULT_PRUNE", "1") != "0") if flag is None else bool(flag)
         d = self.d
         self.enc = BertEncoder(args)
         for t in ("l", "v", "a"):
@@ -768,8 +792,9 @@ class _BPMulTBase(nn.Module):
         return t
 
     def set_prune_unused_rows(self, flag: bool) -> None:
-        """Switch the level-2 / GMU schedule between dense (reference) and rows {0, N-1} only (same logits and
-        gradients).  Launch tables are rebuilt on the next forward."""
+        """Switch between the dense schedule (the reference's) and exact dead-row elimination (the default: level-2 /
+        Fusion-GMU / time-map work on rows {0, N-1} only where nothing else is consumed; same logits and gradients,
+        SURVEY A.10).  Launch tables are rebuilt on the next forward."""
         self.prune_unused_rows = bool(flag)
         self._trunks = {}
 

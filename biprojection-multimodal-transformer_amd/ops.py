@@ -31,6 +31,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class DeviceSeed(int):
+    """A dropout seed the kernels read from device memory when they run (captured graphs): BPM_SEED_INDIRECT | address
+    of a uint64.  Only values of this type may have bit 63 set; a plain int with that bit is rejected below instead of
+    being dereferenced as a pointer on the device."""
+
+    def __new__(cls, tensor: torch.Tensor):
+        if tensor.dtype != torch.int64 or tensor.numel() < 1 or not (tensor.is_cuda or _DRY_RUN):
+            raise ValueError("DeviceSeed: a CUDA int64 tensor holding the seed")
+        return super().__new__(cls, _lib.SEED_INDIRECT | tensor.data_ptr())
+
+
+def _seed(seed: int) -> int:
+    if (seed & _lib.SEED_INDIRECT) and not isinstance(seed, DeviceSeed):
+        raise ValueError("dropout seeds passed by value are 63-bit (bit 63 marks a device-resident seed: ops.DeviceSeed)")
+    return int(seed)
+
+
 # tests/test_plan_tables_cpu.py only: lets the launch TABLES (host logic: pointers, shapes, flags) be built from host
 # tensors without a GPU.  Nothing can be launched from them -- every bpm_* entry point needs device pointers.
 _DRY_RUN = False
@@ -94,7 +111,7 @@ def gemm_grouped(dtype: int, variant: int, probs, seed: int = 0, n: Optional[int
     arr = _as_array(GemmProblem, probs)
     L, s = _lib.lib(), _stream()
     for sub, k in _chunks(arr, GemmProblem, n, GEMM_MAX_GROUP):
-        _lib.check(L.bpm_gemm_grouped(dtype, variant, sub, k, seed, s), "bpm_gemm_grouped")
+        _lib.check(L.bpm_gemm_grouped(dtype, variant, sub, k, _seed(seed), s), "bpm_gemm_grouped")
 
 
 # ----------------------------------------------------------------------------
@@ -116,28 +133,28 @@ def attn_fwd(dtype: int, probs, seed: int = 0) -> None:
     arr = _as_array(AttnProblem, probs)
     L, s = _lib.lib(), _stream()
     for sub, k in _chunks(arr, AttnProblem, None):
-        _lib.check(L.bpm_attn_fwd(dtype, sub, k, seed, s), "bpm_attn_fwd")
+        _lib.check(L.bpm_attn_fwd(dtype, sub, k, _seed(seed), s), "bpm_attn_fwd")
 
 
 def attn_bwd(dtype: int, probs, seed: int = 0) -> None:
     arr = _as_array(AttnProblem, probs)
     L, s = _lib.lib(), _stream()
     for sub, k in _chunks(arr, AttnProblem, None):
-        _lib.check(L.bpm_attn_bwd(dtype, sub, k, seed, s), "bpm_attn_bwd")
+        _lib.check(L.bpm_attn_bwd(dtype, sub, k, _seed(seed), s), "bpm_attn_bwd")
 
 
 def attn_bwd_dq(dtype: int, probs, seed: int = 0) -> None:
     arr = _as_array(AttnProblem, probs)
     L, s = _lib.lib(), _stream()
     for sub, k in _chunks(arr, AttnProblem, None):
-        _lib.check(L.bpm_attn_bwd_dq(dtype, sub, k, seed, s), "bpm_attn_bwd_dq")
+        _lib.check(L.bpm_attn_bwd_dq(dtype, sub, k, _seed(seed), s), "bpm_attn_bwd_dq")
 
 
 def attn_bwd_dkv(dtype: int, probs, seed: int = 0) -> None:
     arr = _as_array(AttnProblem, probs)
     L, s = _lib.lib(), _stream()
     for sub, k in _chunks(arr, AttnProblem, None):
-        _lib.check(L.bpm_attn_bwd_dkv(dtype, sub, k, seed, s), "bpm_attn_bwd_dkv")
+        _lib.check(L.bpm_attn_bwd_dkv(dtype, sub, k, _seed(seed), s), "bpm_attn_bwd_dkv")
 
 
 # ----------------------------------------------------------------------------
@@ -153,13 +170,13 @@ def pack_problem(B, T, Cn, ld, *, src=None, dst=None, g=None, ldg=0, dsrc=None, 
 def pack_rows_fwd(dtype, probs, seed=0) -> None:
     arr = _as_array(PackProblem, probs)
     for sub, k in _chunks(arr, PackProblem, None):
-        _lib.check(_lib.lib().bpm_pack_rows_fwd(dtype, sub, k, seed, _stream()), "bpm_pack_rows_fwd")
+        _lib.check(_lib.lib().bpm_pack_rows_fwd(dtype, sub, k, _seed(seed), _stream()), "bpm_pack_rows_fwd")
 
 
 def pack_rows_bwd(probs, seed=0) -> None:
     arr = _as_array(PackProblem, probs)
     for sub, k in _chunks(arr, PackProblem, None):
-        _lib.check(_lib.lib().bpm_pack_rows_bwd(sub, k, seed, _stream()), "bpm_pack_rows_bwd")
+        _lib.check(_lib.lib().bpm_pack_rows_bwd(sub, k, _seed(seed), _stream()), "bpm_pack_rows_bwd")
 
 
 def pack_weights(dtype, table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:
@@ -210,14 +227,14 @@ def embed_pos_fwd(probs, table, d, scale, seed=0) -> None:
     if table.dtype != torch.float32 or table.shape[1] != d or not table.is_contiguous():
         raise ValueError("embed_pos_fwd: table must be contiguous fp32 [rows, d]")
     for sub, k in _chunks(arr, EmbedProblem, None):
-        _lib.check(_lib.lib().bpm_embed_pos_fwd(sub, k, table.data_ptr(), table.shape[0], d, scale, seed, _stream()),
+        _lib.check(_lib.lib().bpm_embed_pos_fwd(sub, k, table.data_ptr(), table.shape[0], d, scale, _seed(seed), _stream()),
                    "bpm_embed_pos_fwd")
 
 
 def embed_pos_bwd(probs, d, scale, seed=0) -> None:
     arr = _as_array(EmbedProblem, probs)
     for sub, k in _chunks(arr, EmbedProblem, None):
-        _lib.check(_lib.lib().bpm_embed_pos_bwd(sub, k, d, scale, seed, _stream()), "bpm_embed_pos_bwd")
+        _lib.check(_lib.lib().bpm_embed_pos_bwd(sub, k, d, scale, _seed(seed), _stream()), "bpm_embed_pos_bwd")
 
 
 def ln_problem(x, gamma, beta, mean, rstd, R, *, out=None, ldo=0, out_f32=False, dy=None, ldy=0, add=None, dx=None,
@@ -238,6 +255,24 @@ def ln_fwd(dtype, probs, d, eps=1e-5) -> None:
     arr = _as_array(LnProblem, probs)
     for sub, k in _chunks(arr, LnProblem, None):
         _lib.check(_lib.lib().bpm_ln_fwd(dtype, sub, k, d, eps, _stream()), "bpm_ln_fwd")
+
+
+def check_ln_rows(probs, d: int) -> None:
+    """Host-side contract of bpm_ln_bwd_ws for one launch group, checked where the launch TABLES are built (not per
+    step): the dgamma / dbeta / cast_colsum rows ([d] floats each) of its problems are pairwise disjoint.  The last block
+    of a problem adds its partial sums with a plain read-modify-write; the library detects EQUAL row pointers and falls
+    back to atomics, but rows that overlap partially would be summed wrongly without any error."""
+    rows = []
+    for i, p in enumerate(probs):
+        for nm in ("dgamma", "dbeta", "cast_colsum"):
+            a = getattr(p, nm)
+            if a and (nm != "cast_colsum" or p.cast):
+                rows.append((int(a), i, nm))
+    rows.sort()
+    for (a, i, n1), (b, j, n2) in zip(rows, rows[1:]):
+        if b < a + 4 * d:
+            raise ValueError(f"ln_bwd group: {n1} of problem {i} and {n2} of problem {j} share gradient words "
+                             f"(0x{a:x}, 0x{b:x}; rows are {4 * d} bytes): one launch must own each row exactly once")
 
 
 _LN_WS = {}
@@ -264,7 +299,7 @@ def ln_bwd(probs, d, dtype=None, seed=0) -> None:
     for sub, k in _chunks(arr, LnProblem, None):
         ws = _ln_workspace(k, d, dev)
         try:
-            _lib.check(_lib.lib().bpm_ln_bwd_ws(dt, sub, k, d, seed, ws.data_ptr(), ws.numel() * 4, _stream()), "bpm_ln_bwd_ws")
+            _lib.check(_lib.lib().bpm_ln_bwd_ws(dt, sub, k, d, _seed(seed), ws.data_ptr(), ws.numel() * 4, _stream()), "bpm_ln_bwd_ws")
         except RuntimeError:
             _LN_WS.clear()          # an aborted launch may leave ticket words set: start from fresh zeroed workspaces
             raise
@@ -284,7 +319,7 @@ def cast_problem(a, lda, R, Cn, *, a_is_ct=False, b=None, ldb=0, dst_ct=None, ld
 def rows_cast(dtype, probs, seed=0) -> None:
     arr = _as_array(CastProblem, probs)
     for sub, k in _chunks(arr, CastProblem, None):
-        _lib.check(_lib.lib().bpm_rows_cast(dtype, sub, k, seed, _stream()), "bpm_rows_cast")
+        _lib.check(_lib.lib().bpm_rows_cast(dtype, sub, k, _seed(seed), _stream()), "bpm_rows_cast")
 
 
 def addn_problem(out, ins) -> "_lib.AddnProblem":
@@ -333,7 +368,7 @@ def gmu2_bwd(dtype, probs, d) -> None:
 # [B,d] tail: token pick + n-way gated fusion + residual head
 # ----------------------------------------------------------------------------
 def tail_fwd(desc, seed: int = 0) -> None:
-    _lib.check(_lib.lib().bpm_tail_fwd(C.byref(desc), seed, _stream()), "bpm_tail_fwd")
+    _lib.check(_lib.lib().bpm_tail_fwd(C.byref(desc), _seed(seed), _stream()), "bpm_tail_fwd")
 
 
 def tail_bwd(desc, grads) -> None:

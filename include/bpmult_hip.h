@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define BPM_ABI_VERSION 1
+#define BPM_ABI_VERSION 2
 #define BPM_SEED_INDIRECT (1ull << 63) /* seed = BPM_SEED_INDIRECT | (uintptr_t)device pointer to the uint64 seed */
 #define BPM_MAX_GROUP 18 /* problems per grouped launch (6 encoders of a level x 3 projections) */
 #define BPM_GEMM_MAX_GROUP 24 /* bpm_gemm_grouped alone: 6 encoders x (q, k, v, out) weight gradients in one launch */
@@ -373,7 +373,10 @@ int bpm_stream_priority_range(int* least, int* greatest);
  * per-launch durations (ms), work and launch count of one kind, and clears them.
  * ---------------------------------------------------------------------- */
 enum { BPM_PROF_GEMM_NT = 0, BPM_PROF_GEMM_NN = 1, BPM_PROF_GEMM_TN = 2, BPM_PROF_ATTN_FWD = 3,
-       BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5 };
+       BPM_PROF_ATTN_BWD_DQ = 4, BPM_PROF_ATTN_BWD_DKV = 5,
+       /* bpm_gemm_grouped launches that the LDS-DMA kernel takes (hidden >= 512 shapes) are tallied apart from the
+        * 128 x 64 register-staged kernel's (kinds 0-2), so a kind is one kernel */
+       BPM_PROF_GEMM_DMA_NT = 13, BPM_PROF_GEMM_DMA_NN = 14, BPM_PROF_GEMM_DMA_TN = 15 };
 int bpm_prof_enable(unsigned kind_mask);
 int bpm_prof_collect(int kind, double* total_ms, double* total_work, int* launches);
 /* The same, plus the launches' ALGORITHMIC HBM bytes (GEMM: both operands once, the output once, every side operand of

@@ -33,7 +33,7 @@ def test_traffic_file_covers_the_profiled_kernel_families():
             assert t is None or t > 0
     assert b.hbm_traffic("cfg1", "gemm_tn") and b.hbm_traffic("cfg1", "gemm_tn") > 5e7      # committed PMC measurement present
     if os.path.exists(os.path.join(ROOT, "profiles", b.TRAFFIC_FILES["h768"])):
-        assert b.hbm_traffic("h768", "gemm_tn") > 5e7 and b.hbm_traffic("h768", "gemm_nt") > 5e7
+        assert b.hbm_traffic("h768", "gemm_dma_tn") > 5e7 and b.hbm_traffic("h768", "gemm_dma_nt") > 5e7
 
 
 def test_default_workload_is_the_metric_configuration():
@@ -49,7 +49,7 @@ def test_default_workload_is_the_metric_configuration():
 
 def test_workloads_and_cli():
     b = _bench()
-    assert {"cfg1", "cfg3", "h768", "k768"} <= set(b.CONFIGS)
+    assert {"cfg1", "cfg3", "cfg4", "cfg5", "h768", "k768"} <= set(b.CONFIGS)      # every BASELINE.json config has a line
     for c in b.CONFIGS.values():
         assert c["desc"] and c["batch"] >= 1 and len(c["nv"]) == 3
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)

@@ -3,6 +3,7 @@ torch CPU restatements of the same op.  f32 mode must agree to ~1e-5 (exact f32
 MFMA); bf16 mode is compared against the same maths on bf16-rounded operands.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,21 @@ from bpmult_amd.ops import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_RELU, GEMM_N
 
 DEV = "cuda"
 DT = [BPM_F32, BPM_BF16]
+
+
+class lab_library:
+    """The -DBPM_LAB build of the library (tile-configuration / block-pairing overrides; never the product): skip when
+    `__graft_entry__.build()` has not produced it."""
+
+    def __enter__(self):
+        from bpmult_amd import _lib
+        if not os.path.exists(_lib.LAB_LIB_PATH):
+            pytest.skip("build/lab/libbpmult_hip_lab.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+        self.cm = _lib.lab_library()
+        return self.cm.__enter__()
+
+    def __exit__(self, *exc):
+        return self.cm.__exit__(*exc)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -124,10 +140,7 @@ def test_gemm_large_tile_paths_bf16(variant, M, N, K):
 def test_gemm_tall_tile_ragged(variant, M, N, K):
     """The 320 x 256 configuration (picked when it saves a round of workgroups: gemm.hip, tile choice) forced on ragged
     shapes -- rows past M in the last 320-row tile, a k tail, a column tail -- against fp64 on the bf16-rounded operands."""
-    import ctypes as C
     from bpmult_amd import _lib
-    L = _lib.lib()
-    L.bpm_debug_gemm_force.argtypes = [C.c_int]
     pad64 = lambda n: (n + 63) // 64 * 64
     A, Ar = to_ct(rnd(M, K, seed=21), BPM_BF16, pad64(K))
     if variant == GEMM_NT:
@@ -139,12 +152,10 @@ def test_gemm_tall_tile_ragged(variant, M, N, K):
     bias, resid = rnd(N, seed=23).to(DEV), rnd(M, N, seed=24).to(DEV)
     out = torch.full((M, N), float("nan"), device=DEV)
     p = ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N, bias_n=bias, resid=resid, ldr=N, flags=ops.F_KPAD)
-    try:
+    with lab_library() as L:                   # -DBPM_LAB build: the product library has no configuration override
         _lib.check(L.bpm_debug_gemm_force(5), "force")
         ops.gemm_grouped(BPM_BF16, variant, [p, p, p])
         torch.cuda.synchronize()
-    finally:
-        L.bpm_debug_gemm_force(-1)
     close(out, ref + bias.cpu().double() + resid.cpu().double(), 2e-3, f"tall tile v{variant}")
 
 
@@ -152,10 +163,7 @@ def test_gemm_large_tile_epilogues_match_small_tile():
     """Every fused epilogue through the LDS-DMA kernel (wide LDS-transposed stores) against the 128 x 64 kernel on the
     same operands: relu + dropout -> CT, gate + column sums -> CT, head-major scatter (head_dim 128 and 64), += into f32.
     The arithmetic per element is the same, so bf16 outputs may differ by one rounding of a differently ordered sum."""
-    import ctypes as C
     from bpmult_amd import _lib
-    L = _lib.lib()
-    L.bpm_debug_gemm_force.argtypes = [C.c_int]
     M, N, K = 1024, 768, 768
     B_, ctt = 8, torch.bfloat16
     A, _ = to_ct(rnd(M, K, seed=11), BPM_BF16, K)
@@ -164,7 +172,7 @@ def test_gemm_large_tile_epilogues_match_small_tile():
     bias = rnd(N, seed=13).to(DEV)
     base = rnd(M, N, seed=15).to(DEV)
     res = {}
-    try:
+    with lab_library() as L:
         for cfg in (-2, 3, 2, 0, 5):
             _lib.check(L.bpm_debug_gemm_force(cfg), "force")
             o1 = torch.full((M, N), float("nan"), device=DEV).to(ctt)
@@ -181,8 +189,6 @@ def test_gemm_large_tile_epilogues_match_small_tile():
             ops.gemm_grouped(BPM_BF16, GEMM_NT, ps, seed=77)
             torch.cuda.synchronize()
             res[cfg] = [t.float().cpu() for t in (o1, o2, o3, o4, o5, cs)]
-    finally:
-        L.bpm_debug_gemm_force(-1)
     for cfg in (3, 2, 0, 5):
         for i, nm in enumerate(("relu+drop CT", "gate CT", "heads 128", "heads 64", "accum f32", "colsum")):
             close(res[cfg][i], res[-2][i], 1e-2 if i < 4 else 2e-4, f"cfg {cfg} {nm}")
@@ -383,10 +389,7 @@ def test_attention_block_pairing_is_bitwise_neutral(T, S, dh):
     """A workgroup of the attention kernels takes two 64-row blocks (b, nblk-1-b); the tuning hook switches every kernel
     back to one block per workgroup.  Both schedules run the same per-block code, so O, LSE, dQ, dK, dV must be
     bit-identical -- odd block counts (the middle block is alone), one block, masked and with dropout."""
-    import ctypes as C
     from bpmult_amd import _lib
-    L = _lib.lib()
-    L.bpm_debug_attn_pair.argtypes = [C.c_int]
     B, H = 2, 2
     dhp = 32 if dh <= 32 else (64 if dh <= 64 else 128)
     ctt, d = torch.bfloat16, H * dh
@@ -394,7 +397,7 @@ def test_attention_block_pairing_is_bitwise_neutral(T, S, dh):
     mk = lambda L_, seed: torch.cat([rnd(B, H, L_, dh, seed=seed) * 0.5, torch.zeros(B, H, L_, dhp - dh)], -1).to(ctt).to(DEV)
     Q, K, V, dO = mk(T, 41), mk(S, 42), mk(S, 43), mk(T, 44)
     res = {}
-    try:
+    with lab_library() as L:
         for mode in (7, 0):
             _lib.check(L.bpm_debug_attn_pair(mode), "bpm_debug_attn_pair")
             O = torch.zeros(T * B, ld, device=DEV, dtype=ctt)
@@ -406,8 +409,6 @@ def test_attention_block_pairing_is_bitwise_neutral(T, S, dh):
             ops.attn_bwd(BPM_BF16, [p], seed=11)
             torch.cuda.synchronize()
             res[mode] = [t.float().cpu() for t in (O, lse, dQ, dK, dV)]
-    finally:
-        L.bpm_debug_attn_pair(7)
     for a, b, nm in zip(res[7], res[0], ("O", "lse", "dQ", "dK", "dV")):
         assert torch.isfinite(a).all(), nm
         assert torch.equal(a, b), f"{nm}: paired and unpaired schedules differ"
@@ -614,7 +615,10 @@ def test_indirect_seed_draws_the_same_masks():
     from bpmult_amd.ops import F_KPAD
     dtype, seed = BPM_BF16, 0x1234_5678_9ABC_DEF
     sd = torch.tensor([seed], dtype=torch.int64, device=DEV)
-    ind = SEED_INDIRECT | sd.data_ptr()
+    ind = ops.DeviceSeed(sd)
+    assert int(ind) == SEED_INDIRECT | sd.data_ptr()
+    with pytest.raises(ValueError, match="63-bit"):          # a by-value seed with bit 63 set is refused, not dereferenced
+        ops.rows_cast(BPM_F32, [ops.cast_problem(sd.float(), 1, 1, 1, dst_f32=torch.zeros(1, device=DEV), ldf=1)], SEED_INDIRECT | 5)
 
     def both(fn):
         outs = []

@@ -65,8 +65,8 @@ def check(a, b, prec, what, f32_rel=2e-3, f32_abs=None, bf16_rel=BF16_FWD):
 
 
 # measured errors of every whole-model comparison against the reference fixtures, written to
-# gpurun_out/r03_parity_errors.json (copied to profiles/ when committed): the tolerances above are held to <= 2x these
-PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_parity_errors.json")
+# gpurun_out/r04_parity_errors.json (copied to profiles/ when committed): the tolerances above are held to <= 2x these
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r04_parity_errors.json")
 _PARITY = {}
 
 
@@ -86,7 +86,13 @@ def _record(tag, prec, rec):
         pass
 
 
-def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY, BF16_GNORM=1e-1):
+SCHEDULES = [pytest.param(True, id="pruned"), pytest.param(False, id="dense")]
+
+
+def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY, BF16_GNORM=1e-1, prune=False):
+    """Both schedules are held to the SAME reference fixture and the same limits: `prune` = exact dead-row elimination
+    (the library's default), dense = the reference's own schedule."""
+    model.set_prune_unused_rows(prune)
     with torch.no_grad():
         for k, p in model.named_parameters():
             p.copy_(T(det_param(pfx + k, p.shape)))
@@ -120,7 +126,8 @@ def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY, BF16_G
             worst_g = max(worst_g, (err(t.grad, g["gin." + k])[2], "gin." + k))
     rec["worst_grad_norm_rel"] = {"value": worst[0], "param": worst[1]}
     rec["worst_grad_rel_l2"] = {"value": worst_g[0], "tensor": worst_g[1]}
-    _record(pfx, prec, rec)
+    _record(pfx + ("pruned." if prune else "dense."), prec, rec)
+    assert model._trunks[logits.shape[0]].prune == prune
     check(logits, g["logits"], prec, "logits", f32_abs=1e-4 * max(1.0, float(np.abs(g["logits"]).max())))
     check(z, g["z"], prec, "z", f32_abs=1e-4)
     check(loss, g["loss"], prec, "loss", f32_abs=1e-4)
@@ -139,17 +146,20 @@ def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY, BF16_G
     return worst
 
 
+@pytest.mark.parametrize("prune", SCHEDULES)
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_f7_mmtrvat(prec):
+def test_f7_mmtrvat(prec, prune):
     g = load("f7_mmtrvat")
     model = get_model(args_for("mmtrvat", hidden_sz=24, num_heads=4, layers=2, orig_d_l=32))
     assert sorted(k for k, _ in model.named_parameters()) == sorted(g["param_names"].tolist())
     inputs = {"xl": T(det("f7.xl", (2, 50, 32))), "img": T(det("f7.img", (2, 500, 35))), "aud": T(det("f7.aud", (2, 375, 74)))}
-    run_model(g, model, "f7.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec)
+    run_model(g, model, "f7.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec,
+              prune=prune)
 
 
+@pytest.mark.parametrize("prune", SCHEDULES)
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_f8_mmtrvapt(prec):
+def test_f8_mmtrvapt(prec, prune):
     g = load("f8_mmtrvapt")
     model = get_model(args_for("mmtrvapt", hidden_sz=24, num_heads=4, layers=2, orig_d_l=32, orig_d_v=40, orig_d_a=96,
                                orig_d_p=64, n_classes=13))
@@ -157,22 +167,24 @@ def test_f8_mmtrvapt(prec):
     inputs = {"xl": T(det("f8.xl", (2, 60, 32))), "img": T(det("f8.img", (2, 150, 40))),
               "aud": T(det("f8.aud", (2, 96, 1000))), "post": T(det("f8.post", (2, 64)))}
     run_model(g, model, "f8.", inputs,
-              lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], d["post"], output_gate=True), prec)
+              lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], d["post"], output_gate=True), prec, prune=prune)
 
 
+@pytest.mark.parametrize("prune", SCHEDULES)
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_f9_cfg1_shape(prec):
+def test_f9_cfg1_shape(prec, prune):
     """d=300, 12 heads (head_dim 25), 8 layers, lengths padded to 512, B=2."""
     g = load("f9_cfg1")
     model = get_model(args_for("mmtrvat"))
     inputs = {"xl": T(det("f9.xl", (2, 20, 768))), "img": T(det("f9.img", (2, 500, 35))), "aud": T(det("f9.aud", (2, 400, 74)))}
     run_model(g, model, "f9.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec,
-              BF16_GRAD=BF16_GRAD)
+              BF16_GRAD=BF16_GRAD, prune=prune)
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "f10_cfg3.npz")), reason="f10 fixture not generated")
+@pytest.mark.parametrize("prune", SCHEDULES)
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_f10_cfg3_shape(prec):
+def test_f10_cfg3_shape(prec, prune):
     """BASELINE.json configs[2] dims: 4-modal mmtrvapt, d=768, 6 heads (head_dim 128: the multi-tile attention forward /
     dQ / dK-dV kernels at T=512 / S=200 and 200 / 512), 5 layers, orig_d_v=4096 (K=4096 projection GEMM), biprojection
     level 2, time-axis maps, B=1.  Logits, gates, loss, every parameter's gradient norm and the small gradients."""
@@ -190,7 +202,7 @@ def test_f10_cfg3_shape(prec):
 
     # bf16 mode, stated: gradient norms within 1.5e-1 here (five biprojection layers at head_dim 128: measured worst
     # 1.1e-1 on one level-2 in_proj_weight); the f32 mode holds every norm to 5e-3
-    run_model(g, model, "f10.", inputs, call, prec, BF16_GRAD=1.5e-1, BF16_GNORM=1.5e-1)
+    run_model(g, model, "f10.", inputs, call, prec, BF16_GRAD=1.5e-1, BF16_GNORM=1.5e-1, prune=prune)
     for k in ("xl", "img", "aud"):                      # big inputs: gradient norms only
         n = dev[k].grad.double().norm().item()
         ref = float(g["ginn." + k][0])
@@ -198,8 +210,9 @@ def test_f10_cfg3_shape(prec):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "f11_h768.npz")), reason="f11 fixture not generated")
+@pytest.mark.parametrize("prune", SCHEDULES)
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_f11_headline(prec):
+def test_f11_headline(prec, prune):
     """The bench's headline workload against the reference itself (mmtr.py:587-866): 3-modal mmtrvat, d=768, 12 heads
     (head_dim 64), 8 layers, orig_d 768/35/74, L/V/A = 20/500/400 -> 512, B=1.  Logits, gates, loss, every parameter's
     gradient norm, the small gradients and the input gradients."""
@@ -208,7 +221,7 @@ def test_f11_headline(prec):
     assert sorted(k for k, _ in model.named_parameters()) == sorted(g["param_names"].tolist())
     inputs = {"xl": T(det("f11.xl", (1, 20, 768))), "img": T(det("f11.img", (1, 500, 35))), "aud": T(det("f11.aud", (1, 400, 74)))}
     run_model(g, model, "f11.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec,
-              BF16_GRAD=BF16_GRAD, BF16_GNORM=BF16_GNORM_BIG)
+              BF16_GRAD=BF16_GRAD, BF16_GNORM=BF16_GNORM_BIG, prune=prune)
 
 
 def test_fused_adam_matches_torch_adam():
@@ -265,15 +278,27 @@ def test_fused_adam_kernel_exact():
         assert d <= 2e-6, (it, d)
 
 
+@pytest.mark.parametrize("model", ["mmtrvat", "mmtrvapt", "mmtrvapt_1layer"])
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_pruned_level2_schedule_is_exact(prec):
-    """computing only query rows {0, N-1} in the level-2 encoders and the Fusion-GMUs gives the same
-    logits, gates and gradients as the dense schedule (dropout off: the two schedules draw different masks)."""
+def test_pruned_schedule_equals_dense_schedule(prec, model):
+    """SURVEY A.10 on random weights with non-trivial LayerNorm affines (the fixtures' are the reference's initial 1 / 0):
+    the pruned schedule -- 3-modal: level-2 encoders and Fusion-GMUs on query rows {0, N-1}; 4-modal: the last
+    biprojection layer's query side, the Fusion-GMUs and the time-map outputs on those rows -- gives the same logits,
+    gates and gradients (parameters and inputs) as the dense schedule (dropout off: the two draw different masks)."""
     import copy
     torch.manual_seed(11)
-    a = args_for("mmtrvat", hidden_sz=48, num_heads=4, layers=3, orig_d_l=32, num_vectors_l=96, num_vectors_a=96,
-                 num_vectors_v=96)
+    four = model.startswith("mmtrvapt")
+    kw = dict(hidden_sz=48, num_heads=4, layers=1 if model.endswith("1layer") else 3, orig_d_l=32)
+    if four:
+        a = args_for("mmtrvapt", orig_d_v=40, orig_d_a=96, orig_d_p=64, n_classes=13, num_vectors_l=96, num_vectors_a=56,
+                     num_vectors_v=56, **kw)
+        xs = [torch.randn(2, 40, 32), torch.randn(2, 50, 40), torch.randn(2, 96, 700), torch.randn(2, 64)]
+    else:
+        a = args_for("mmtrvat", num_vectors_l=96, num_vectors_a=96, num_vectors_v=96, **kw)
+        xs = [torch.randn(2, 40, 32), torch.randn(2, 96, 35), torch.randn(2, 77, 74)]
     m1 = get_model(a)
+    if four:
+        m1.audio_enc.conv_layers[2] = torch.nn.AdaptiveAvgPool1d(56)
     with torch.no_grad():
         for p in m1.parameters():
             if p.dim() == 1:
@@ -281,13 +306,13 @@ def test_pruned_level2_schedule_is_exact(prec):
     m2 = copy.deepcopy(m1)
     m1.precision = m2.precision = prec
     m1, m2 = m1.cuda().train(), m2.cuda().train()
+    m1.set_prune_unused_rows(False)
     m2.set_prune_unused_rows(True)
-    xs = [torch.randn(2, 40, 32), torch.randn(2, 96, 35), torch.randn(2, 77, 74)]
-    tgt = (torch.randn(2, 6) > 0).float().cuda()
+    tgt = (torch.randn(2, a.n_classes) > 0).float().cuda()
     outs = []
     for m in (m1, m2):
         x = [t.clone().cuda().requires_grad_(True) for t in xs]
-        logits, z = m(x[0], None, None, x[1], x[2], output_gate=True)
+        logits, z = m(x[0], None, None, *x[1:], output_gate=True)
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, tgt)
         loss.backward()
         outs.append((logits.detach(), z.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},

@@ -31,14 +31,23 @@ def dry_run():
         ops._DRY_RUN = False
 
 
+@pytest.mark.parametrize("prune", [True, False])
 @pytest.mark.parametrize("model,kw", [("mmtrvat", {}), ("mmtrvat", {"hidden_sz": 40, "precision": "f32"}),
                                       ("mmtrvapt", {"orig_d_a": 96, "num_vectors_a": 40, "num_vectors_v": 40}),
                                       ("mmtrvapt", {"orig_d_a": 96, "hidden_sz": 40, "num_vectors_a": 40, "num_vectors_v": 40})])
-def test_launch_tables_build_from_host_tensors(dry_run, model, kw):
-    m = get_model(_args(model, **kw))
+def test_launch_tables_build_from_host_tensors(dry_run, model, kw, prune):
+    """Both schedules: dense (the reference's) and exact dead-row elimination (the default)."""
+    m = get_model(_args(model, prune_unused_rows=prune, **kw))
     st = m._ensure_store()
     trunk = m._trunk_for(2)
+    assert trunk.prune == prune
     L = m.layers
+    if prune:                                    # level 2 / GMU / time-map outputs shrink to rows {0, N-1}
+        for n, b in zip(trunk.out2, trunk.plan2.buf):
+            assert trunk.out2[n].shape[0] == 2 and b["Rl"][-1] == 2 * 2
+            assert b["tailp"] == (model == "mmtrvapt") and (b["Rl"][0] == b["R"] or L == 1 or model == "mmtrvat")
+        assert all(t["out"].shape[0] == 2 for t in trunk.tmap.values())
+        assert all(g["R"] == 2 * 2 for g in trunk.g.values())
     for plan in (trunk.plan1, trunk.plan2):
         assert set(plan._bwd) == {(t, f) for t in (True, False) for f in (True, False)}
         for training in (True, False):

@@ -49,7 +49,7 @@ def main():
     dev, ct = "cuda", torch.bfloat16
     if a.pair >= 0:
         from bpmult_amd import _lib
-        _lib.check(_lib.lib().bpm_debug_attn_pair(a.pair), "bpm_debug_attn_pair")
+        _lib.check(_lib.lab_library().__enter__().bpm_debug_attn_pair(a.pair), "bpm_debug_attn_pair")   # -DBPM_LAB build only
     B, H, T, S, dh, G = a.B, a.H, a.T, a.S, a.dh, a.G
     dhp = 32 if dh <= 32 else 64 if dh <= 64 else 128
     d = H * dh

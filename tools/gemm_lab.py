@@ -5,7 +5,7 @@ configuration (cfg 0..), median of --iters launches on random data.
 
   python tools/gemm_lab.py [--d 768] [--rows 4096] [--G 6] [--check-only] [--time-only]
 
-Uses the tuning hook bpm_debug_gemm_force (not part of the C ABI header)."""
+Uses the tuning hook bpm_debug_gemm_force of the -DBPM_LAB build (not in the product library or the C ABI header)."""
 import argparse
 import os
 import sys
@@ -25,10 +25,20 @@ NCFG = 6
 NAMES = {-1: "auto", -2: "tiled", 0: "128x128 4w", 1: "256x128 8w", 2: "256x256 8w", 3: "256x256 16w", 4: "128x128 ns3", 5: "320x256 8w"}
 
 
+_LAB = None
+
+
 def force(cfg):
-    L = _lib.lib()
-    L.bpm_debug_gemm_force.argtypes = [_lib.C.c_int]
-    _lib.check(L.bpm_debug_gemm_force(cfg), "bpm_debug_gemm_force")
+    """The override lives in the -DBPM_LAB build only (build/lab/libbpmult_hip_lab.so, or BPMULT_LIB = a lab variant):
+    this process's launches are routed through it from the first call on."""
+    global _LAB
+    if _LAB is None:
+        if os.environ.get("BPMULT_LIB"):
+            _LAB = _lib.lib()
+            _LAB.bpm_debug_gemm_force.argtypes = [_lib.C.c_int]
+        else:
+            _LAB = _lib.lab_library().__enter__()
+    _lib.check(_LAB.bpm_debug_gemm_force(cfg), "bpm_debug_gemm_force")
 
 
 def pad(n, q=64):
