@@ -153,6 +153,11 @@ class ZeroDesc(C.Structure):
     _fields_ = [("p", C.c_void_p), ("n", C.c_uint), ("blk0", C.c_uint)]
 
 
+class AdamSeg(C.Structure):
+    _fields_ = [("off4", C.c_size_t), ("n4", C.c_uint), ("blk0", C.c_uint), ("dst", C.c_void_p),
+                ("rows", C.c_int), ("cols", C.c_int), ("dst_ld", C.c_int), ("pad_", C.c_int)]
+
+
 class EmbedProblem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("T", C.c_int), ("B", C.c_int), ("accumulate", C.c_int),
                 ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("pos0", C.c_int), ("pos_stride", C.c_int)]
@@ -239,6 +244,8 @@ SIGNATURES = {
     "bpm_tail_fwd": [C.POINTER(TailDesc), _U64, _P],
     "bpm_tail_bwd": [C.POINTER(TailDesc), C.POINTER(TailGrads), _P],
     "bpm_adam_step": [_P, _P, _P, _P, C.c_size_t, _F, _F, _F, _F, _F, _I, _F, _I, _P],
+    "bpm_adam_blocks": [C.c_size_t],
+    "bpm_adam_step_table": [_I, _P, _I, C.c_uint, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _I, _P],
     "bpm_stream_create": [_I, C.POINTER(C.c_void_p)],
     "bpm_stream_priority_range": [C.POINTER(_I), C.POINTER(_I)],
     "bpm_prof_enable": [C.c_uint],

@@ -876,6 +876,69 @@ extern "C" int bpm_adam_step(float* param, float* grad, float* exp_avg, float* e
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The same step, table driven, writing the CT weight shadows as it stores the updated masters (no second pass over the
+// flat master for the shadow refresh: 2.7 GB read + 1.35 GB written per optimizer step at hidden 768).  The flat buffer
+// is cut into segments (device-resident table, built once): runs of parameters without a plain shadow, and one segment per
+// parameter that has one -- a whole [rows, cols] matrix whose shadow is [rows, dst_ld], pad columns left as they are
+// (zero since allocation).  A block covers ADAM_CHUNK consecutive f32x4 of ONE segment, so the segment is looked up once
+// per block; every thread has its 4 x 4 loads in flight before the first use.
+// ---------------------------------------------------------------------------
+constexpr int ADAM_ITER = 4;
+constexpr int ADAM_CHUNK = NT * ADAM_ITER;             // f32x4 per block
+
+template <typename CT>
+__global__ __launch_bounds__(NT) void adam_table_kernel(const bpm_adam_seg* __restrict__ tab, int nseg, float* __restrict__ p,
+                                                       float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                       float lr_c, float b1, float b2, float eps, float wd, float rsq_bc2,
+                                                       float gscale, int zero_grad) {
+    const bpm_adam_seg S = find_desc(tab, nseg, blockIdx.x);
+    const size_t base = S.off4 + (size_t)(blockIdx.x - S.blk0) * ADAM_CHUNK;
+    const size_t end = S.off4 + S.n4;
+    f32x4 pp[ADAM_ITER], gg[ADAM_ITER], mm[ADAM_ITER], vv[ADAM_ITER];
+#pragma unroll
+    for (int j = 0; j < ADAM_ITER; ++j) {
+        const size_t i = base + j * NT + threadIdx.x;
+        const size_t ic = i < end ? i : S.off4;             // clamped, unconditional loads
+        pp[j] = ((const f32x4*)p)[ic]; gg[j] = ((const f32x4*)g)[ic]; mm[j] = ((const f32x4*)m)[ic]; vv[j] = ((const f32x4*)v)[ic];
+    }
+#pragma unroll
+    for (int j = 0; j < ADAM_ITER; ++j) {
+        const size_t i = base + j * NT + threadIdx.x;
+        if (i >= end) continue;
+        f32x4 x = pp[j], gr = gg[j] * gscale + wd * pp[j];
+        const f32x4 mo = b1 * mm[j] + (1.f - b1) * gr;
+        const f32x4 vo = b2 * vv[j] + (1.f - b2) * gr * gr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] -= lr_c * mo[q] / (sqrtf(vo[q]) * rsq_bc2 + eps);
+        ((f32x4*)p)[i] = x; ((f32x4*)m)[i] = mo; ((f32x4*)v)[i] = vo;
+        if (zero_grad) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (S.dst) {
+            const size_t e = 4 * (i - S.off4);               // element index inside the [rows, cols] matrix; cols % 4 == 0
+            if (e < (size_t)S.rows * S.cols) {               // (the segment's 64-element alignment tail has no shadow)
+                size_t o = e;
+                if (S.cols != S.dst_ld) { const size_t r = e / (unsigned)S.cols; o = r * S.dst_ld + (e - r * S.cols); }
+                put4<CT>(S.dst, o, x);
+            }
+        }
+    }
+}
+
+extern "C" int bpm_adam_blocks(size_t n4) { return (int)((n4 + ADAM_CHUNK - 1) / ADAM_CHUNK); }
+
+extern "C" int bpm_adam_step_table(int dtype, const bpm_adam_seg* table_dev, int nseg, unsigned total_blocks, float* param, float* grad,
+                                   float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    if (!table_dev || nseg < 1 || total_blocks < 1 || !param || !grad || !exp_avg || !exp_avg_sq || step < 1) return BPM_ERR_ARG;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return BPM_ERR_ALIGN;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    BPM_DISPATCH_CT(dtype, adam_table_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, nseg, param, grad,
+                    exp_avg, exp_avg_sq, (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale,
+                    zero_grad);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int bpm_fold_bias(const bpm_fold_desc* table_dev, int ndesc, unsigned total_blocks, void* stream) {
     if (!table_dev || ndesc < 1 || total_blocks < 1) return BPM_ERR_ARG;
     hipLaunchKernelGGL(fold_bias_kernel, dim3(total_blocks), dim3(NT), 0, (hipStream_t)stream, table_dev, ndesc);

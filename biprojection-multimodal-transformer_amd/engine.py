@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
-from ._lib import (BPM_BF16, AddnProblem, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
+from ._lib import (BPM_BF16, AdamSeg, AddnProblem, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
                    AttnProblem, CastProblem, FoldDesc, GemmProblem, LnProblem, PackDesc,
                    UnfoldDesc)
 from .ops import pad32
@@ -243,7 +243,9 @@ class ParamStore:
         if descs:
             arr = (PackDesc * len(descs))(*descs)
             raw = bytes(memoryview(arr))
-            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            self._table = self._table if ops._DRY_RUN else self._table.to(self.device)
+        self._build_adam_table()
         self.fold_flat = torch.zeros(max(self._fold_total, 64), device=self.device, dtype=torch.float32)
         fd, blk = [], 0
         for (wname, row0, rows, cols, beta, bias, bias_off, off) in self._fold_specs:
@@ -259,6 +261,73 @@ class ParamStore:
             fd.append(f)
         self._nfold, self._fold_blk = len(fd), blk
         self._fold_table = ops.device_table(fd) if fd else None
+
+    def _build_adam_table(self) -> None:
+        """Segment table of the fused optimizer step (bpm_adam_step_table) and the pack table of what it leaves over.
+        A shadow is written BY THE OPTIMIZER KERNEL when it is the plain CT copy of a whole parameter matrix (the large
+        encoder matrices, the projections, the GMU hidden maps, the time maps); shadows that mix two parameters (the K / V
+        projection weights with their LayerNorm gain folded in) or re-arrange columns (the x_gate halves) stay with a second,
+        small pack_weights launch (`_rest_table`), as do the folded biases."""
+        esz = 2 if self.dtype == BPM_BF16 else 4
+        plain, rest = {}, []
+        for spec in self._shadow_specs:
+            (name, rows, cols, ld, src_ld, dst_ld, src_off, off, colscale) = spec
+            p = self.params[name]
+            if (colscale is None and src_off == 0 and src_ld == cols and rows * cols == p.numel() and cols % 4 == 0
+                    and name not in plain and (off * esz) % 16 == 0 and dst_ld % 4 == 0):
+                plain[name] = (rows, cols, dst_ld, off)
+            else:
+                rest.append(spec)
+        descs, blk = [], 0
+        for (name, rows, cols, ld, src_ld, dst_ld, src_off, off, colscale) in rest:
+            d = PackDesc()
+            d.src = self.params[name].data_ptr() + 4 * src_off
+            d.dst = self.shadow_flat.data_ptr() + esz * off
+            d.rows, d.cols, d.ld, d.src_ld, d.dst_ld, d.blk0 = rows, cols, ld, src_ld, dst_ld, blk
+            d.colscale = self.params[colscale].data_ptr() if colscale else None
+            blk += (rows * ld + 1023) // 1024
+            descs.append(d)
+        self._rest_table = (ops.device_table(descs), len(descs), blk) if descs else None
+        nblk = ops.adam_blocks
+        segs, blk, run = [], 0, None              # run = [off, end) of consecutive parameters without a plain shadow
+        for n in self.names:
+            a = self.off[n]
+            b = a + (self.params[n].numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if n in plain:
+                if run is not None:
+                    segs.append((run[0], run[1], None))
+                    run = None
+                segs.append((a, b, plain[n]))
+            elif run is None:
+                run = [a, b]
+            else:
+                run[1] = b
+        if run is not None:
+            segs.append((run[0], run[1], None))
+        assert segs and segs[0][0] == 0 and segs[-1][1] == self.total and all(x[1] == y[0] for x, y in zip(segs, segs[1:]))
+        out = []
+        for a, b, sh in segs:
+            sg = AdamSeg()
+            sg.off4, sg.n4, sg.blk0 = a // 4, (b - a) // 4, blk
+            if sh is not None:
+                rows, cols, dst_ld, off = sh
+                sg.dst, sg.rows, sg.cols, sg.dst_ld = self.shadow_flat.data_ptr() + esz * off, rows, cols, dst_ld
+            blk += nblk((b - a) // 4)
+            out.append(sg)
+        self._adam_table = (ops.device_table(out), len(out), blk)
+        self._adam_plain = plain
+
+    def adam_step(self, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                  zero_grad: bool) -> None:
+        """One launch: torch.optim.Adam's update of every trunk parameter (flat master / gradient / moments) AND the CT
+        shadows of the plain weight matrices, written from the updated values as they are stored.  What is left for the
+        next forward's refresh_shadows is the small rest (K / V weights with the LayerNorm gain folded in, folded biases)."""
+        tab, nseg, nblk = self._adam_table
+        ops.adam_step_table(self.dtype, tab, nseg, nblk, self.master, self.gflat, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
+                            weight_decay, step, grad_scale, zero_grad)
+        # every plain shadow now holds the CT image of its updated master (whatever was pending before the step); the rest
+        # (shadows that mix parameters, folded biases) is stale until the next refresh_shadows
+        self._dirty, self._dirty_rest, self._shadow_sig = False, True, self._versions()
 
     def sptr(self, key: str, elem_off: int = 0) -> int:
         return self.shadow_flat.data_ptr() + self.shadow_flat.element_size() * (self._shadow_off[key] + elem_off)
@@ -286,11 +355,15 @@ class ParamStore:
         since the last refresh (an optimizer step, load_state_dict, any in-place edit: torch's per-tensor version
         counters, or mark_dirty() for raw-pointer writers).  In a training loop that is once per optimizer step."""
         sig = self._versions()
-        if not force and not getattr(self, "_dirty", True) and sig == getattr(self, "_shadow_sig", None):
+        full = force or getattr(self, "_dirty", True) or sig != getattr(self, "_shadow_sig", None)
+        if not full and not getattr(self, "_dirty_rest", False):
             return
-        self._dirty, self._shadow_sig = False, sig
-        if self._table is not None:
-            ops.pack_weights(self.dtype, self._table, self._ndesc, self._nblk)
+        self._dirty, self._dirty_rest, self._shadow_sig = False, False, sig
+        if full:
+            if self._table is not None:
+                ops.pack_weights(self.dtype, self._table, self._ndesc, self._nblk)
+        elif self._rest_table is not None:         # after a fused optimizer step: it wrote the plain shadows itself
+            ops.pack_weights(self.dtype, *self._rest_table)
         if self._fold_table is not None:
             ops.fold_bias(self._fold_table, self._nfold, self._fold_blk)
 
@@ -347,6 +420,17 @@ _SIDE_PRIORITY_ENV = os.environ.get("BPMULT_SIDE_PRIORITY", "auto")
 # main stream's row kernels never queue behind weight-gradient workgroups: 47-51 ms/step against 32.5.  Also without
 # effect: d(LayerNorm output) written as bf16 by the data-gradient GEMMs and read as bf16 by the LayerNorm backward --
 # 75 MB less per launch pair, 31.2 -> 31.3 ms/step.)
+
+
+# Side streams that hold work the main stream has not waited for yet (handle -> stream).  Inside a graph capture every such
+# fork must be joined back into the capturing stream before the capture ends -- an unjoined one invalidates the capture
+# (and crashed inside hipStreamEndCapture in round 3 with a second stream pair).  _run() adds on SIDE / SIDE2 and clears on
+# JOIN; the graph code checks that nothing is left (open_forks) before it lets a capture end.
+_OPEN_FORKS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def open_forks() -> List["torch.cuda.Stream"]:
+    return list(_OPEN_FORKS.values())
 
 
 def _side_stream(device, which: int = 1, low: bool = True) -> "torch.cuda.Stream":
@@ -666,16 +750,20 @@ class EncoderGroupPlan:
                     ev.record(side)
                     main.wait_event(ev)
                     side_dirty = False
+                    _OPEN_FORKS.pop(side.cuda_stream, None)
             elif s[0] is SIDE2:                     # third stream: starts right behind the main stream's last launch
                 side2 = _side_stream(main.device, 2, self._side_low)
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side2.wait_event(ev)
+                _OPEN_FORKS[side2.cuda_stream] = side2
                 with torch.cuda.stream(side2):
                     self._exec(s[1], seed)
                 ev2 = torch.cuda.Event()
                 ev2.record(side2)
-                side.wait_event(ev2)                # the side stream's later steps consume its output
+                side.wait_event(ev2)                # the side stream's later steps consume its output: joined through it
+                _OPEN_FORKS.pop(side2.cuda_stream, None)
+                _OPEN_FORKS[side.cuda_stream] = side
                 side_dirty = True
             elif s[0] is SIDE:
                 if main_dirty:
@@ -683,6 +771,7 @@ class EncoderGroupPlan:
                     ev.record(main)
                     side.wait_event(ev)
                     main_dirty = False
+                _OPEN_FORKS[side.cuda_stream] = side
                 with torch.cuda.stream(side):
                     self._exec(s[1], seed)
                 side_dirty = True

@@ -112,6 +112,9 @@ class BertEncoder(nn.Module):
 
 
 # ----------------------------------------------------------------------------
+_RETIRED_GRAPHS: list = []       # captured graphs of dropped trunks: kept alive, never replayed (see _Trunk.MAX_GRAPHS)
+
+
 class _Trunk:
     """Device buffers + launch tables of the hot path for one batch size."""
 
@@ -530,6 +533,19 @@ class _Trunk:
     # (part of the key), attaching .grad views.  Used when nothing needs the eager launch order: no gradient-exchange
     # hook (GradSync runs eagerly: its all-reduces interleave with backward), launch profiler off.
     GRAPH_WARMUP = 2            # eager runs of a key before it is captured (lazy allocations, stream creation)
+    # Bounded caches.  The reference collate pads text to the batch's longest sentence and trims audio to its shortest
+    # clip (data/helpers.py:83-102), so real training sees hundreds of (L, V, A) keys, and every captured graph pins its
+    # static inputs / outputs and every allocation made during its capture.  At most MAX_GRAPHS keys are ever captured
+    # (forward graph + its backward graphs): the first ones to recur GRAPH_WARMUP times; every other key runs as eager
+    # launches (the step time is the same: DESIGN.md section 4).  Call counters are kept for MAX_TRACKED keys.
+    # Captured graphs are NEVER DESTROYED while the process lives: on this stack (torch 2.10 + ROCm 7.0/7.2) destroying a
+    # captured graph and then capturing / launching others ends in a host segfault inside hipGraphLaunch
+    # (tools/graph_cache_probe.py, profiles/r04_graph_probe.json: 5 of 5 evicting variants crash -- shared or per-key pool,
+    # with or without a device synchronise, either capture mode -- 0 of 2 non-evicting ones; round 3's capture_end crash
+    # had the same ingredients).  So there is no LRU eviction, and a trunk that is dropped (another batch size, .to())
+    # parks its graph objects in _RETIRED_GRAPHS after releasing their static tensors.
+    MAX_GRAPHS = 4
+    MAX_TRACKED = 64
 
     def _seed_handle(self, seed: int) -> int:
         if getattr(self, "_seed_dev", None) is None:
@@ -537,31 +553,101 @@ class _Trunk:
         self._seed_dev.fill_(seed)
         return ops.DeviceSeed(self._seed_dev)
 
+    def _graph_state(self) -> None:
+        if getattr(self, "_fg", None) is None:
+            from collections import OrderedDict
+            self._fg, self._bg, self._gpool = OrderedDict(), OrderedDict(), torch.cuda.graph_pool_handle()
+            self.graph_stats = {"captured": 0, "evicted": 0, "failed": 0}
+            self.MAX_GRAPHS = int(os.environ.get("BPMULT_MAX_GRAPHS", self.MAX_GRAPHS))
+
+    def _evict_graphs(self) -> None:
+        """Forget the oldest call counters of keys that hold no graph (see MAX_TRACKED); captured graphs stay."""
+        idle = [k for k, e in self._fg.items() if "graph" not in e]
+        for k in idle[:max(0, len(idle) - self.MAX_TRACKED)]:
+            del self._fg[k]
+            for bk in [bk for bk in self._bg if bk[0] == k]:
+                del self._bg[bk]
+
+    def _may_capture(self) -> bool:
+        return sum("graph" in e for e in self._fg.values()) < self.MAX_GRAPHS
+
+    def retire_graphs(self) -> None:
+        """This trunk is being dropped: park its captured graphs (never destroyed while the process lives, see above) and
+        release everything else they pinned."""
+        park = os.environ.get("BPMULT_GRAPH_DESTROY", "0") != "1"      # (=1: tools/graph_cache_probe.py reproduces the crash)
+        for table in (getattr(self, "_fg", None) or {}, getattr(self, "_bg", None) or {}):
+            for e in table.values():
+                if "graph" in e and park:
+                    _RETIRED_GRAPHS.append(e["graph"])
+                e.clear()
+        self._fg = self._bg = None
+
+    def _capture(self, fn):
+        """Capture fn() into a new graph.  thread_local error mode: the backward capture runs on the autograd thread while
+        other threads (a DataLoader's pin_memory thread, an asynchronous checkpoint copy) may call into HIP.  Every side
+        stream forked inside the capture must have been joined back when fn returns: an unjoined fork is joined here and
+        reported as a Python error after the capture has ended -- not left for hipStreamEndCapture to trip over.
+        Returns (graph, result) or raises; the caller marks the key non-capturable and goes on eagerly."""
+        from .. import engine as _e
+        from ..engine import open_forks
+        g = torch.cuda.CUDAGraph()
+        left = []
+        _e._OPEN_FORKS.clear()                                    # (forks of earlier eager runs are not this capture's)
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g, pool=self._gpool, capture_error_mode="thread_local"):
+                try:
+                    res = fn()
+                finally:
+                    left = open_forks()
+                    for st_ in left:                              # join, so that the capture can end cleanly
+                        torch.cuda.current_stream().wait_stream(st_)
+        finally:
+            self._capturing = False
+            _e._OPEN_FORKS.clear()
+        if left:
+            raise RuntimeError(f"graph capture: {len(left)} side stream(s) were still forked when the launch sequence ended "
+                               "(a step table without its JOIN)")
+        return g, res
+
     def graph_forward(self, feats: Dict[str, torch.Tensor], extra: Optional[torch.Tensor], seed: int, training: bool, want_grad: bool):
         """Forward pass through a captured graph when one exists (or can be captured now) for this key; returns
         (logits, z, key) or None (the caller then runs eagerly)."""
         key = (training, tuple(tuple(feats[k].shape) for k in ("l", "v", "a")), extra is not None)
-        if getattr(self, "_fg", None) is None:
-            self._fg, self._bg, self._gpool = {}, {}, torch.cuda.graph_pool_handle()
+        self._graph_state()
         ent = self._fg.setdefault(key, {"calls": 0})
+        self._fg.move_to_end(key)
         ent["calls"] += 1
+        if ent.get("failed"):
+            return None
         if "graph" not in ent:
-            if ent["calls"] <= self.GRAPH_WARMUP:
+            if ent["calls"] <= self.GRAPH_WARMUP or not self._may_capture():
+                self._evict_graphs()
                 return None
             ent["in"] = {k: torch.empty_like(feats[k]) for k in ("l", "v", "a")}
             ent["extra"] = torch.empty_like(extra) if extra is not None else None
             handle = self._seed_handle(seed)
-            g = torch.cuda.CUDAGraph()
-            self._capturing = True
+
+            def run():
+                self.forward(ent["in"], handle, training)
+                return self.tail_forward(ent["extra"], handle, training)
+
             try:
-                with torch.cuda.graph(g, pool=self._gpool):
-                    self.forward(ent["in"], handle, training)
-                    ent["out"] = self.tail_forward(ent["extra"], handle, training)
-            finally:
-                self._capturing = False
-            ent["graph"] = g
+                ent["graph"], ent["out"] = self._capture(run)
+            except Exception as exc:                      # noqa: BLE001 -- any capture failure: this key runs eagerly from now on
+                import warnings
+                ent.clear()
+                ent.update(calls=self.GRAPH_WARMUP + 1, failed=True)
+                self._px_rows = {k: self.N[k] for k in self.N}      # nothing of the capture ran: clear the pad rows again
+                self.graph_stats["failed"] += 1
+                warnings.warn(f"BPMulT: graph capture of the forward pass failed for input shapes {key[1]} ({exc}); "
+                              "this shape runs as eager launches")
+                torch.cuda.synchronize()
+                return None
+            self.graph_stats["captured"] += 1
             # host-side state a forward leaves for its backward (a replay runs no Python): restored before the backward
             ent["state"] = (self._conv, self._tail_desc, self.plan1._last, self.plan2._last)
+            self._evict_graphs()
         for k in ("l", "v", "a"):
             ent["in"][k].copy_(feats[k])
         if extra is not None:
@@ -578,22 +664,36 @@ class _Trunk:
     def graph_backward(self, fkey, dlogits: torch.Tensor, dz: Optional[torch.Tensor], params, seed: int, need: Dict[str, bool]):
         """Backward of a graph-run forward.  Whether the gradients start from zero (first-writer-stores launch tables +
         the small tensors cleared) or accumulate is part of the key.  Returns (parameter gradients of the tail, d(extra),
-        d(features)) as clones of the graph's static outputs, or None before the key is captured."""
+        d(features)) as clones of the graph's static outputs, or None before the key is captured (or when its capture
+        failed: the caller runs the eager backward -- the forward state has been restored)."""
         self.restore_forward_state(fkey)
         fresh = self.st._fresh()
         key = (fkey, fresh, dz is not None, tuple(sorted(k for k, v in need.items() if v)))
         ent = self._bg.setdefault(key, {"calls": 0})
         ent["calls"] += 1
+        if ent.get("failed"):
+            return None
         if "graph" not in ent:
             if ent["calls"] <= 1:
                 return None
             ent["dlogits"] = torch.empty_like(dlogits)
             ent["dz"] = torch.empty_like(dz) if dz is not None else None
             handle = self._seed_handle(seed)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._gpool):
+
+            def run():
                 pg, dextra = self.tail_backward(ent["dlogits"], ent["dz"], params)
-                res = self.backward(None, handle, need, stores=fresh)
+                return pg, dextra, self.backward(None, handle, need, stores=fresh)
+
+            try:
+                g, (pg, dextra, res) = self._capture(run)
+            except Exception as exc:                      # noqa: BLE001
+                import warnings
+                ent.clear()
+                ent.update(calls=2, failed=True)
+                self.graph_stats["failed"] += 1
+                warnings.warn(f"BPMulT: graph capture of the backward pass failed ({exc}); this key runs as eager launches")
+                torch.cuda.synchronize()
+                return None
             ent.update(graph=g, pg=pg, dextra=dextra, res=res)
         ent["dlogits"].copy_(dlogits)
         if dz is not None:
@@ -724,8 +824,20 @@ class _BPMulTBase(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._store, self._trunks = None, {}
+        self._drop_trunks()
+        self._store = None
         return r
+
+    def _drop_trunks(self) -> None:
+        for t in getattr(self, "_trunks", {}).values():
+            t.retire_graphs()
+        self._trunks = {}
+
+    def __del__(self):
+        try:
+            self._drop_trunks()
+        except Exception:                  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def _ensure_store(self) -> ParamStore:
         if self._store is None or not self._store.still_flat():
@@ -775,7 +887,8 @@ class _BPMulTBase(nn.Module):
                     st.add_shadow(lin + ".weight", lin + ".weight", w.shape[0], w.shape[1])
             st.finalize_shadows()
             st.set_store_written([w for n in ENC_ORDER for w in EncoderGroupPlan.store_written(n + ".", self.layers)])
-            self._store, self._trunks = st, {}
+            self._drop_trunks()
+            self._store = st
             self._anchor = torch.zeros(1, device=st.device, requires_grad=True)
         return self._store
 
@@ -786,7 +899,7 @@ class _BPMulTBase(nn.Module):
         t = self._trunks.pop(B, None)
         if t is None:
             while len(self._trunks) >= self.MAX_TRUNKS:
-                self._trunks.pop(next(iter(self._trunks)))         # least recently used
+                self._trunks.pop(next(iter(self._trunks))).retire_graphs()         # least recently used
             t = _Trunk(self, B)
         self._trunks[B] = t                                         # (re)insert as most recent
         return t
@@ -796,7 +909,7 @@ class _BPMulTBase(nn.Module):
         Fusion-GMU / time-map work on rows {0, N-1} only where nothing else is consumed; same logits and gradients,
         SURVEY A.10).  Launch tables are rebuilt on the next forward."""
         self.prune_unused_rows = bool(flag)
-        self._trunks = {}
+        self._drop_trunks()
 
     def _next_seed(self) -> int:
         """Dropout seed of the next forward pass: (process seed, data-parallel rank, step).  Ranks that seed alike

@@ -134,7 +134,7 @@ class TransformerEncoder(nn.Module):
 
     def _next_seed(self) -> int:
         self._step += 1
-        return (torch.initial_seed() * 1000003 + self._step) & 0xFFFFFFFFFFFFFFFF
+        return (torch.initial_seed() * 1000003 + self._step) & 0x7FFFFFFFFFFFFFFF      # 63 bits: bit 63 marks a device-resident seed
 
     def forward(self, x_in, x_in_k=None, x_in_v=None):
         if x_in_k is None or x_in_v is None:

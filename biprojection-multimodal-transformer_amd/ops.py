@@ -190,6 +190,20 @@ def device_table(descs) -> torch.Tensor:
     return t if _DRY_RUN else t.to("cuda")
 
 
+def adam_blocks(n4: int) -> int:
+    return int(_lib.lib().bpm_adam_blocks(n4)) if not _DRY_RUN else (n4 + 1023) // 1024
+
+
+def adam_step_table(dtype, table_dev, nseg, nblk, master, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step,
+                    grad_scale, zero_grad) -> None:
+    for t in (master, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != master.numel():
+            raise ValueError("adam_step_table: flat contiguous float32 buffers of one size")
+    _lib.check(_lib.lib().bpm_adam_step_table(dtype, table_dev.data_ptr(), nseg, nblk, _p(master), _p(grad), _p(exp_avg), _p(exp_avg_sq),
+                                              lr, beta1, beta2, eps, weight_decay, step, grad_scale, int(bool(zero_grad)), _stream()),
+               "bpm_adam_step_table")
+
+
 def fold_bias(table_dev: torch.Tensor, ndesc: int, total_blocks: int) -> None:
     _lib.check(_lib.lib().bpm_fold_bias(table_dev.data_ptr(), ndesc, total_blocks, _stream()), "bpm_fold_bias")
 

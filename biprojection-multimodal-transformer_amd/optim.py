@@ -79,11 +79,10 @@ class FusedAdam(torch.optim.Optimizer):
         n = st.master.numel()
         if n % 4:
             raise RuntimeError("flat parameter buffer is not a multiple of 4 elements")
-        _lib.check(_lib.lib().bpm_adam_step(st.master.data_ptr(), st.gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n,
-                                            g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                                            self.step_count, grad_scale, int(self.fused_zero_grad),
-                                            torch.cuda.current_stream().cuda_stream), "bpm_adam_step")
-        st.mark_dirty()                                    # masters changed through raw pointers: CT shadows are stale
+        # one launch: the update of every trunk parameter AND the CT shadows of the plain weight matrices, written from
+        # the updated masters as they are stored (no second pass over the flat master for the next forward's operands)
+        st.adam_step(self._m, self._v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count,
+                     grad_scale, self.fused_zero_grad)
         if self._tail_opt is not None:
             for tg in self._tail_opt.param_groups:
                 tg["lr"], tg["betas"], tg["eps"], tg["weight_decay"] = g["lr"], g["betas"], g["eps"], g["weight_decay"]

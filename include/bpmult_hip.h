@@ -357,6 +357,25 @@ int bpm_tail_bwd(const bpm_tail_desc* t, const bpm_tail_grads* g, void* stream);
 int bpm_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
 
+/* The same step over the same flat buffers, table driven, WRITING THE CT WEIGHT SHADOWS as it stores the updated masters
+ * (train.py:396-398 followed by the next forward's weight casts: one pass instead of two over the flat master).  The table
+ * (device memory, built once) cuts the flat buffer into consecutive segments: off4 / n4 in units of 4 floats (16-byte
+ * aligned), blk0 = first block (a segment takes bpm_adam_blocks(n4) blocks; entries sorted by blk0, covering the buffer).
+ * dst != NULL: the segment starts with a whole [rows, cols] fp32 matrix (cols % 4 == 0) whose CT shadow is [rows, dst_ld];
+ * shadow element (r, c) = CT(updated master (r, c)), pad columns are not touched.  dtype = the shadows' CT. */
+typedef struct bpm_adam_seg {
+    size_t off4;
+    unsigned n4;
+    unsigned blk0;
+    void* dst;
+    int rows, cols, dst_ld;
+    int pad_;
+} bpm_adam_seg;
+int bpm_adam_blocks(size_t n4);
+int bpm_adam_step_table(int dtype, const bpm_adam_seg* table_dev, int nseg, unsigned total_blocks, float* param, float* grad,
+                        float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, float grad_scale, int zero_grad, void* stream);
+
 /* Engine plumbing (no reference counterpart): a non-blocking HIP stream at the device's lowest priority
  * (low_priority != 0) or at the default priority.  The host engine puts weight-gradient GEMMs and the
  * key/value-side chain there so that the dispatcher serves the critical-path stream first. */

@@ -302,10 +302,12 @@ def _model_fixture(name, model, pfx, call, inputs, n_classes, full_grads, small_
     save(name, **out)
 
 
-def _three_modal(name, pfx, d, H, Ly, B, L, V, A, odl, small_only=False):
+def _three_modal(name, pfx, d, H, Ly, B, L, V, A, odl, small_only=False, nv=None):
     torch.manual_seed(0)
     args = _args(hidden_sz=d, num_heads=H, layers=Ly, orig_d_l=odl)
     model = mmtr.MultiprojectionMMTransformer3DGMUClf(args)
+    if nv is not None:                                     # the padded lengths are source constants (mmtr.py:664-670): set on the instance
+        model.num_vectors_l = model.num_vectors_a = model.num_vectors_v = nv
     model.train()                                          # all dropout rates are 0
     xl = leaf(pfx + "xl", (B, L, odl))
     img, aud = leaf(pfx + "img", (B, V, 35)), leaf(pfx + "aud", (B, A, 74))
@@ -328,6 +330,13 @@ def f11_h768():
     (head_dim 64), 8 layers, orig_d 768/35/74 (proj_l skipped: mmtr.py:748), L/V/A = 20/500/400 -> 512, B=1.  680 M
     parameters: logits, gates, loss, every parameter's gradient norm, the small full gradients, the input gradients."""
     _three_modal("f11_h768", "f11.", 768, 12, 8, 1, 20, 500, 400, 768, small_only=True)
+
+
+def f12_k768():
+    """The north-star kernel-point model (BASELINE.json north_star: hidden 768 / seq_len 50; bench.py `k768`): `mmtrvat` at
+    d=768, 6 heads (head_dim 128), 5 layers, every modality 50 time steps (num_vectors_* = 50: T = S = 50 in all twelve
+    encoders, strictly causal masks), B=2.  The unused time-axis maps keep the reference's 512 x 512 shapes (no gradient)."""
+    _three_modal("f12_k768", "f12.", 768, 6, 5, 2, 50, 50, 50, 768, small_only=True, nv=50)
 
 
 def f8_mmtrvapt():
@@ -405,7 +414,7 @@ def f10_cfg3():
 
 
 ALL = dict(f1=f1_posemb, f2=f2_mask, f3=f3_mha, f4=f4_layer, f5=f5_encoder, f6=f6_gmu,
-           f7=f7_mmtrvat, f8=f8_mmtrvapt, f9=f9_cfg1, f10=f10_cfg3, f11=f11_h768)
+           f7=f7_mmtrvat, f8=f8_mmtrvapt, f9=f9_cfg1, f10=f10_cfg3, f11=f11_h768, f12=f12_k768)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -224,6 +224,22 @@ def test_f11_headline(prec, prune):
               BF16_GRAD=BF16_GRAD, BF16_GNORM=BF16_GNORM_BIG, prune=prune)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "f12_k768.npz")), reason="f12 fixture not generated")
+@pytest.mark.parametrize("prune", SCHEDULES)
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_f12_kernel_point_model(prec, prune):
+    """The north-star kernel-point model against the reference itself (BASELINE.json north_star: hidden 768 / seq_len 50;
+    bench.py `k768` and `kernel_point`): `mmtrvat` at d=768, 6 heads (head_dim 128), 5 layers, T = S = 50 in all twelve
+    encoders (num_vectors_* = 50: single-tile attention, strictly causal masks), B=2."""
+    g = load("f12_k768")
+    model = get_model(args_for("mmtrvat", hidden_sz=768, num_heads=6, layers=5, num_vectors_l=50, num_vectors_a=50,
+                               num_vectors_v=50))
+    assert sorted(k for k, _ in model.named_parameters()) == sorted(g["param_names"].tolist())
+    inputs = {"xl": T(det("f12.xl", (2, 50, 768))), "img": T(det("f12.img", (2, 50, 35))), "aud": T(det("f12.aud", (2, 50, 74)))}
+    run_model(g, model, "f12.", inputs, lambda m, d: m(d["xl"], None, None, d["img"], d["aud"], output_gate=True), prec,
+              BF16_GRAD=BF16_GRAD, BF16_GNORM=1e-1, prune=prune)
+
+
 def test_fused_adam_matches_torch_adam():
     """bpmult_amd.optim.FusedAdam (one kernel over the flat trunk buffers) == torch.optim.Adam, three steps,
     including the hand-off through refreshed weight shadows (the loss sequence must match too)."""
@@ -254,6 +270,51 @@ def test_fused_adam_matches_torch_adam():
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         worst = max(worst, float((p1.detach() - p2.detach()).abs().max()))
     assert worst <= 3e-3, worst
+
+
+@pytest.mark.parametrize("prec,d", [("bf16", 64), ("bf16", 40), ("f32", 40)])
+@pytest.mark.parametrize("four", [False, True])
+def test_fused_adam_writes_the_weight_shadows(prec, d, four):
+    """The optimizer kernel stores the CT shadows of the plain weight matrices as it stores the updated masters; the small
+    rest (K / V weights with the LayerNorm gain folded in, x_gate halves, folded biases) follows at the next forward's
+    refresh.  Together they must be bit-equal to a full re-derivation from the masters (pack_weights + fold_bias), with
+    and without column padding (d = 40: leading dimension 64), for both models; and the next forward uses them."""
+    from bpmult_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    kw = dict(hidden_sz=d, num_heads=4, layers=2, orig_d_l=32, num_vectors_l=48, num_vectors_a=48, num_vectors_v=48)
+    if four:
+        m = get_model(args_for("mmtrvapt", orig_d_v=40, orig_d_a=96, orig_d_p=64, n_classes=13, **kw))
+        m.audio_enc.conv_layers[2] = torch.nn.AdaptiveAvgPool1d(48)
+        x = [torch.randn(2, 17, 32), torch.randn(2, 30, 40), torch.randn(2, 96, 600), torch.randn(2, 64)]
+    else:
+        m = get_model(args_for("mmtrvat", **kw))
+        x = [torch.randn(2, 17, 32), torch.randn(2, 48, 35), torch.randn(2, 31, 74)]
+    m.precision = prec
+    m = m.cuda().train()
+    x = [t.cuda() for t in x]
+    opt = FusedAdam(m, lr=1e-2, weight_decay=0.01)
+    for it in range(2):
+        opt.zero_grad()
+        m(x[0], None, None, *x[1:]).square().mean().backward()
+        opt.step()
+        st = m._store
+        assert st._dirty_rest and not st._dirty and len(st._adam_plain) > 50
+        st.refresh_shadows()                                    # the rest pass only
+        got, gotf = st.shadow_flat.clone(), st.fold_flat.clone()
+        st.refresh_shadows(force=True)                          # full re-derivation from the masters
+        assert torch.equal(got, st.shadow_flat), f"step {it}: optimizer-written shadows differ from pack_weights"
+        assert torch.equal(gotf, st.fold_flat)
+    # a write to a parameter between steps still forces the full refresh (version counters), and the optimizer then
+    # rewrites every plain shadow from the updated master
+    with torch.no_grad():
+        m.trans_l_with_a.layers[0].fc1.weight.mul_(0.5)
+    opt.zero_grad()
+    m(x[0], None, None, *x[1:]).square().mean().backward()
+    opt.step()
+    m._store.refresh_shadows()
+    got = m._store.shadow_flat.clone()
+    m._store.refresh_shadows(force=True)
+    assert torch.equal(got, m._store.shadow_flat)
 
 
 def test_fused_adam_kernel_exact():
@@ -435,6 +496,110 @@ def test_graph_replay_equals_eager_launches(prec):
             assert torch.equal(m1(xa[0], None, None, xa[1], xa[2]), m2(xa[0], None, None, xa[1], xa[2]))
 
 
+@pytest.mark.skipif(os.environ.get("BPMULT_GRAPH", "1") == "0", reason="graph replay switched off by BPMULT_GRAPH=0")
+def test_graph_cache_is_bounded_under_varying_lengths():
+    """The reference collate pads text to the batch's longest sentence and trims audio to its shortest clip
+    (data/helpers.py:83-102): training sees many (L, V, A) shapes.  At most MAX_GRAPHS of them are ever captured (with their
+    backward graphs); the others run as eager launches, device memory stops growing, and results stay equal to the eager
+    launch sequence throughout.  (No eviction: destroying captured graphs crashes later launches on this stack,
+    tools/graph_cache_probe.py.)"""
+    import copy
+    m1 = _toy()
+    m2 = copy.deepcopy(m1)
+    m1, m2 = m1.cuda().train(), m2.cuda().train()
+    m1.use_graphs, m2.use_graphs = False, True
+    tgt = (torch.randn(2, 6, generator=torch.Generator().manual_seed(1)) > 0).float().cuda()
+    lossf = torch.nn.functional.binary_cross_entropy_with_logits
+    base = _toy_inputs(seed=4)
+    lengths = [10, 11, 12, 13, 14, 15, 16]
+
+    def step(m, L):
+        for p in m.parameters():
+            p.grad = None
+        x = [base[0][:, :L].contiguous(), base[1], base[2]]
+        out = m(x[0], None, None, x[1], x[2])
+        lossf(out, tgt).backward()
+        return out.detach().clone(), m.trans_l_with_a.layers[0].fc1.weight.grad.detach().clone()
+
+    step(m2, lengths[0])
+    t2 = m2._trunks[2]
+    t2.MAX_GRAPHS = 3
+    mem = []
+    for rnd_ in range(3):
+        for L in lengths:
+            for _ in range(4):                      # 4 calls per shape: the first MAX_GRAPHS shapes are captured on their 3rd
+                a, b = step(m1, L), step(m2, L)
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (rnd_, L)
+            assert sum("graph" in e for e in t2._fg.values()) <= 3
+        torch.cuda.synchronize()
+        mem.append(torch.cuda.memory_allocated())
+    captured = sorted(k[1][0][1] for k, e in t2._fg.items() if "graph" in e)
+    assert captured == lengths[:3], captured
+    assert t2.graph_stats["captured"] == 3 and t2.graph_stats["failed"] == 0
+    assert mem[2] <= mem[1] + (1 << 20), f"device memory keeps growing with the number of shapes seen: {mem}"
+    t2.MAX_TRACKED = 2
+    step(m2, 17)
+    assert sum("graph" not in e for e in t2._fg.values()) <= 2 and sum("graph" in e for e in t2._fg.values()) == 3
+
+
+@pytest.mark.skipif(os.environ.get("BPMULT_GRAPH", "1") == "0", reason="graph replay switched off by BPMULT_GRAPH=0")
+def test_dropped_trunks_park_their_graphs_and_new_ones_replay():
+    """A trunk is dropped when a third batch size shows up (MAX_TRUNKS = 2), on .to() / set_prune_unused_rows(): its captured
+    graphs are parked in _RETIRED_GRAPHS (destroying them is what crashes later launches on this stack) and the static
+    tensors they pinned are released.  New trunks then capture and replay their own graphs with the eager results."""
+    import copy
+    from bpmult_amd.models import bpmult as BM
+    m1 = _toy()
+    m2 = copy.deepcopy(m1)
+    m1, m2 = m1.cuda().train(), m2.cuda().train()
+    m1.use_graphs, m2.use_graphs = False, True
+    lossf = torch.nn.functional.binary_cross_entropy_with_logits
+    n0 = len(BM._RETIRED_GRAPHS)
+    for rnd_ in range(2):
+        for B in (2, 3, 1):                                     # three batch sizes: every switch past the second drops a trunk
+            x = _toy_inputs(B=B, seed=20 + B)
+            tgt = (torch.randn(B, 6, generator=torch.Generator().manual_seed(B)) > 0).float().cuda()
+            for it in range(4):
+                outs = []
+                for m in (m1, m2):
+                    for p in m.parameters():
+                        p.grad = None
+                    out = m(x[0], None, None, x[1], x[2])
+                    lossf(out, tgt).backward()
+                    outs.append((out.detach().clone(), m.trans_v_with_a.layers[1].fc2.weight.grad.detach().clone()))
+                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (rnd_, B, it)
+            assert any("graph" in e for e in m2._trunks[B]._fg.values())
+    assert len(m2._trunks) == 2
+    assert len(BM._RETIRED_GRAPHS) >= n0 + 2 * 4 - 2, "dropped trunks must park their forward + backward graphs"
+
+
+@pytest.mark.skipif(os.environ.get("BPMULT_GRAPH", "1") == "0", reason="graph replay switched off by BPMULT_GRAPH=0")
+def test_unjoined_side_stream_fails_the_capture_in_python_and_falls_back_to_eager():
+    """A launch table that forks the side stream and never joins it back (here: the level-2 forward table -- the last one
+    to use the side stream -- with its JOIN removed) must not reach hipStreamEndCapture unjoined: the capture joins the stream, ends, reports the key as
+    non-capturable (a warning), and the step runs as eager launches with the right result."""
+    import copy
+    m1 = _toy()
+    m2 = copy.deepcopy(m1)
+    m1, m2 = m1.cuda().eval(), m2.cuda().eval()
+    m1.use_graphs, m2.use_graphs = False, True
+    x = _toy_inputs()
+    with torch.no_grad():
+        ref = m1(x[0], None, None, x[1], x[2])
+        m2(x[0], None, None, x[1], x[2])
+        t2 = m2._trunks[2]
+        from bpmult_amd import engine
+        assert t2.plan2._fwd[False][-1] is engine.JOIN
+        t2.plan2._fwd[False] = t2.plan2._fwd[False][:-1]
+        m2(x[0], None, None, x[1], x[2])
+        with pytest.warns(UserWarning, match="graph capture of the forward pass failed"):
+            out = m2(x[0], None, None, x[1], x[2])          # third call of the key: capture attempted
+        assert t2.graph_stats["failed"] == 1 and not any("graph" in e for e in t2._fg.values())
+        assert torch.equal(out, ref)
+        assert torch.equal(m2(x[0], None, None, x[1], x[2]), ref)      # and stays eager, silently
+    engine._OPEN_FORKS.clear()
+
+
 def test_master_level_writes_refresh_the_weight_shadows():
     """The bf16 / f32 GEMM operands are shadows of the flat fp32 master, re-derived when the masters change.  A write
     through the flat master itself (dist.broadcast(master), EMA on the master) bumps no parameter's version counter:
@@ -551,7 +716,7 @@ def _randn(*s, seed):
 def test_full_size_configs_properties(name):
     """BASELINE.json configs[3] (CMU-MOSEI shape: 3-modal, d=300, 12 heads, 8 layers, L/V/A = 50/500/500 -> 512, the
     per-GPU batch of 64) and configs[4] (stress: 4-modal, d=1536, 12 heads -> head_dim 128, seq_len 512 per modality,
-    5 layers) at FULL size through the HIP path, bf16.  The reference cannot be run at these sizes in a test, so the
+    5 layers, per-GPU batch 8) at FULL size through the HIP path, bf16, default (pruned) schedule.  The reference cannot be run at these sizes in a test, so the
     checks are size-independent properties of the model: finite outputs of the right shape; train mode with every
     dropout rate 0 equals eval mode exactly (the only train/eval difference is dropout); gradients accumulate (two
     backward passes without clearing == twice one pass); parameters the graph never touches get no gradient; and rows of
@@ -564,7 +729,7 @@ def test_full_size_configs_properties(name):
     else:
         a = _prop_args("mmtrvapt", hidden_sz=1536, num_heads=12, layers=5, orig_d_l=768, orig_d_v=4096, orig_d_a=96, orig_d_p=4096,
                        n_classes=13, num_vectors_l=512, num_vectors_a=512, num_vectors_v=512)
-        B = 2
+        B = 8                                                 # the configuration's per-GPU batch
         ins = [_randn(B, 512, 768, seed=1), _randn(B, 512, 4096, seed=2), _randn(B, 96, 2600, seed=3), _randn(B, 4096, seed=4)]
         nc, unused = 13, ()
     torch.manual_seed(3)

@@ -265,3 +265,32 @@ def test_f11_headline_shape_logits():
         logits, z = O.bpmult3_forward(sd, m, xl, img, aud)
     close(logits, g["logits"], 1e-4, "logits")
     close(z, g["z"], 1e-4, "z")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "f12_k768.npz")), reason="f12 fixture not generated")
+def test_f12_kernel_point_model():
+    """The north-star kernel-point model from the reference (BASELINE.json north_star: hidden 768 / seq_len 50; bench.py
+    `k768`): `mmtrvat` at d=768, 6 heads (head_dim 128), 5 layers, 50 time steps per modality (num_vectors_* = 50, set on
+    the reference instance), B=2 -- logits, gates, loss and a few gradient norms through the oracle's backward."""
+    g = load("f12_k768")
+    pfx = "f12."
+    m = O.ModelCfg(768, 6, 5, 6, orig_d_l=768, num_vectors_l=50, num_vectors_a=50, num_vectors_v=50)
+    shapes = O.model_param_shapes(m, False)
+    ref = dict(zip(g["param_names"].tolist(), g["param_shapes"].tolist()))
+    mine = {k: ",".join(map(str, v)) for k, v in shapes.items()}
+    assert mine.keys() == ref.keys()
+    # (the unused time-axis maps keep the reference's source-constant 512 x 512 shapes there)
+    assert {k: v for k, v in mine.items() if not k.startswith("transfm_")} == {k: v for k, v in ref.items() if not k.startswith("transfm_")}
+    sd = {k: T(det_param(pfx + k, s)).requires_grad_(True) for k, s in shapes.items()}
+    xl, img, aud = (T(det(pfx + n, s)) for n, s in (("xl", (2, 50, 768)), ("img", (2, 50, 35)), ("aud", (2, 50, 74))))
+    logits, z = O.bpmult3_forward(sd, m, xl, img, aud)
+    close(logits, g["logits"], 1e-4, "logits")
+    close(z, g["z"], 1e-4, "z")
+    tgt = (T(det(pfx + "tgt", tuple(logits.shape))) > 0).float()
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, tgt)
+    close(loss, g["loss"], 1e-5, "loss")
+    loss.backward()
+    for k in ("trans_l_with_a.layers.0.fc1.weight", "trans_v_with_l2a.layers.4.self_attn.in_proj_weight", "gmu_l.x_gate.weight",
+              "proj_v.weight", "out_layer.bias"):
+        n = sd[k].grad.double().norm().item()
+        assert abs(n - g["gn." + k][0]) <= 1e-3 * g["gn." + k][0], (k, n, g["gn." + k][0])
