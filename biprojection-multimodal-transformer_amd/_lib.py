@@ -27,7 +27,7 @@ ABI_VERSION = 2                   # == BPM_ABI_VERSION of include/bpmult_hip.h; 
 # -DBPM_LAB build: the same kernels plus the two process-global tuning hooks (bpm_debug_gemm_force / bpm_debug_attn_pair)
 # that tools/gemm_lab.py, tools/attn_lab.py and three kernel tests use; never loaded by the product path
 LAB_LIB_PATH = os.path.join(_HERE, "..", "build", "lab", "libbpmult_hip_lab.so")
-BPM_F32, BPM_BF16 = 0, 1
+BPM_F32, BPM_BF16, BPM_BF16X3 = 0, 1, 2      # BPM_BF16X3: bpm_gemm_grouped only (split-bf16 operands, three products)
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
 F_ACCUM, F_RELU, F_ATOMIC, F_KPAD, F_BACKGROUND = 1, 2, 4, 8, 16     # F_KPAD = BPM_GEMM_KPAD_ZERO
@@ -158,6 +158,10 @@ class AdamSeg(C.Structure):
                 ("rows", C.c_int), ("cols", C.c_int), ("dst_ld", C.c_int), ("pad_", C.c_int)]
 
 
+class SplitProblem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R", C.c_int), ("C", C.c_int), ("ld", C.c_int), ("ldp", C.c_int)]
+
+
 class EmbedProblem(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("T", C.c_int), ("B", C.c_int), ("accumulate", C.c_int),
                 ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("pos0", C.c_int), ("pos_stride", C.c_int)]
@@ -235,6 +239,7 @@ SIGNATURES = {
     "bpm_ln_bwd_ws_bytes": [_I, _I],
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_add_n": [C.POINTER(AddnProblem), _I, _P],
+    "bpm_split_rows": [C.POINTER(SplitProblem), _I, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_signal_pack": [_I, _P, _P, _I, _I, _I, C.c_int64, C.c_int64, C.c_int64, _I, _I, C.c_int64, _I, _P],

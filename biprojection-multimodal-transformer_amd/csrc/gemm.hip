@@ -742,19 +742,19 @@ int launch(int variant, bool fast, bool bm64, const Group& g, hipStream_t s) {
     return 0;
 }
 
-// LDS-DMA kernel configurations: (waves along m, waves along n, m tiles per wave, stages)
-template <int WMD, int WND, int TMW, int NS>
+// LDS-DMA kernel configurations: (waves along m, waves along n, m tiles per wave, stages); X3: split-bf16 operands
+template <int WMD, int WND, int TMW, int NS, bool X3 = false>
 int launch_dma_cfg(int variant, const Group& g, hipStream_t s) {
     dim3 grid(g.total_tiles), block(64 * WMD * WND);
     switch (variant) {
-        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_dma_kernel<true, true, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
-        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_dma_kernel<true, false, WMD, WND, TMW, NS>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_dma_kernel<true, true, WMD, WND, TMW, NS, false, X3>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_dma_kernel<true, false, WMD, WND, TMW, NS, false, X3>), grid, block, 0, s, g); break;
         case BPM_GEMM_TN:
             if constexpr ((16 * TMW * WMD) % 128 == 0) {
                 bool xs = false;
                 for (int i = 0; i < g.nprob; ++i) xs = xs || g.p[i].colsum_x != nullptr;
-                if (xs) hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, true>), grid, block, 0, s, g);
-                else hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, false>), grid, block, 0, s, g);
+                if (xs) hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, true, X3>), grid, block, 0, s, g);
+                else hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, false, X3>), grid, block, 0, s, g);
             } else return BPM_ERR_ARG;         // k-strided X: 128-column sub-images only
             break;
         default: return BPM_ERR_ARG;
@@ -768,7 +768,15 @@ constexpr DmaCfg DMA_CFGS[] = {{128, 128}, {256, 128}, {256, 256}, {256, 256}, {
 constexpr int CFG_TALL = 5;               // 320-row tiles (k-contiguous X only): see the tile choice in bpm_gemm_grouped
 constexpr int N_DMA_CFGS = sizeof(DMA_CFGS) / sizeof(DMA_CFGS[0]);
 
-int launch_dma(int cfg, int variant, const Group& g, hipStream_t s) {
+int launch_dma(int cfg, int variant, const Group& g, hipStream_t s, bool x3 = false) {
+    if (x3) {                                 // the configurations the automatic choice picks (fewer instantiations)
+        switch (cfg) {
+            case 2: return launch_dma_cfg<2, 4, 8, 2, true>(variant, g, s);
+            case 3: return launch_dma_cfg<4, 4, 4, 2, true>(variant, g, s);
+            case CFG_TALL: return launch_dma_cfg<2, 4, 10, 2, true>(variant, g, s);
+        }
+        return BPM_ERR_ARG;
+    }
     switch (cfg) {
         case 0: return launch_dma_cfg<2, 2, 4, 2>(variant, g, s);      // 128 x 128,  4 waves, 2 stages (64 KB: 2 per CU)
         case 1: return launch_dma_cfg<4, 2, 4, 2>(variant, g, s);      // 256 x 128,  8 waves
@@ -820,7 +828,11 @@ extern "C" int bpm_debug_trace(unsigned long long* out, int nblocks) {
 extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs, int nprob, uint64_t seed, void* stream) {
     if (nprob < 1 || nprob > BPM_GEMM_MAX_GROUP || !probs) return BPM_ERR_ARG;
     if (variant != BPM_GEMM_NT && variant != BPM_GEMM_NN && variant != BPM_GEMM_TN) return BPM_ERR_ARG;
-    const int sz = dtype == BPM_BF16 ? 2 : 4;
+    // BPM_BF16X3: A / B are split-bf16 images (bpm_split_rows: lda / ldb span the hi and the lo plane), K / M / N are those
+    // of the fp32 product, CT outputs and the gate operand are fp32; only the LDS-DMA kernel computes it
+    const bool x3 = dtype == BPM_BF16X3;
+    if (dtype != BPM_F32 && dtype != BPM_BF16 && !x3) return BPM_ERR_ARG;
+    const int sz = dtype == BPM_F32 ? 4 : 2;
     const bool xk = variant != BPM_GEMM_TN, yk = variant == BPM_GEMM_NT;
     // hardware-bounded loader: every problem promises zero k padding, k-contiguous rows are whole k stages and the
     // matrices fit 31-bit byte offsets
@@ -846,7 +858,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     // 47, d(k/v) 135 -> 107, FFN weight gradients 445 -> 322 (8 waves of 128 x 64); the attention weight gradients
     // (768 x 768 x 4096: nine 256 x 256 tiles per problem) stay on the 128 x 64 kernel (154 against 186).
     int dma = -1;
-    if (dtype == BPM_BF16 && fast && g_force_dma != -2) {
+    if ((dtype == BPM_BF16 || x3) && fast && (g_force_dma != -2 || x3)) {
         bool legal = true, big = true;
         long tiles_tn = 0;
         for (int i = 0; i < nprob && legal; ++i) {
@@ -854,6 +866,11 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
             const long kceil = ((long)q.K + DK - 1) / DK * DK;
             legal = q.splitk <= 1 && !(q.flags & BPM_GEMM_ATOMIC) && (!xk || (q.flags & BPM_GEMM_A_OVERLAP) || kceil <= q.lda) &&
                     (!yk || (q.flags & BPM_GEMM_B_OVERLAP) || kceil <= q.ldb);
+            if (x3) {       // a plane (half the leading dimension) holds whole k stages / whole 128-column sub-images, no overlap
+                const long pa = q.lda / 2, pb = q.ldb / 2, m128 = ((long)q.M + 127) / 128 * 128, n128 = ((long)q.N + 127) / 128 * 128;
+                legal = legal && !(q.flags & (BPM_GEMM_A_OVERLAP | BPM_GEMM_B_OVERLAP)) && (q.lda & 1) == 0 && (q.ldb & 1) == 0 &&
+                        (xk ? kceil <= pa : m128 <= pa) && (yk ? kceil <= pb : n128 <= pb) && (pa * 2) % 16 == 0 && (pb * 2) % 16 == 0;
+            }
             // its epilogue is the 4-wide one only (epi_fast_ok, evaluated here on the host)
             const uintptr_t al = (uintptr_t)q.bias_n | (uintptr_t)q.resid | (uintptr_t)q.C | (uintptr_t)q.gate;
             legal = legal && (q.N & 3) == 0 && (al & 15) == 0 && ((q.ldr | q.ldc | q.ldg) & 3) == 0 && !q.bias_m &&
@@ -865,8 +882,10 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         }
         // weight gradients: one 256 x 256 tile per CU only pays when most CUs get one (measured, 768 x 768 x 4096 problems
         // with bias column sums: 24 problems = 216 tiles 227 -> 181 us, 18 = 162 tiles 169 -> 156, 12 = 108 tiles 114 -> ~150)
-        if (variant == BPM_GEMM_TN && tiles_tn * 8 < num_cus() * 5) big = false;
-        if (legal && g_force_dma >= 0) dma = g_force_dma == CFG_TALL && variant == BPM_GEMM_TN ? -1 : g_force_dma;
+        if (variant == BPM_GEMM_TN && tiles_tn * 8 < num_cus() * 5 && !x3) big = false;
+        if (x3 && !legal) return BPM_ERR_ARG;
+        if (x3) big = true;                       // the caller (ops.gemm_grouped) sends what bpm_gemm_x3_eligible accepted
+        if (legal && g_force_dma >= 0 && !x3) dma = g_force_dma == CFG_TALL && variant == BPM_GEMM_TN ? -1 : g_force_dma;
         else if (legal && big) {
             dma = variant == BPM_GEMM_TN ? 2 : 3;
             if (variant != BPM_GEMM_TN) {
@@ -945,7 +964,8 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         if (q.out_kind == BPM_OUT_F32 && (q.flags & BPM_GEMM_ACCUM)) bytes += mn * 4;
     }
     BpmProfScope prof((dma >= 0 ? BPM_K_GEMM_DMA_NT : BPM_K_GEMM_NT) + variant, s, flops, bytes);
-    if (dma >= 0) return launch_dma(dma, variant, g, s);
+    if (x3 && dma < 0) return BPM_ERR_ARG;
+    if (dma >= 0) return launch_dma(dma, variant, g, s, x3);
     return dtype == BPM_BF16 ? launch<bf16_t>(variant, fast, bm_tile == 64, g, s)
                              : launch<float>(variant, fast, bm_tile == 64, g, s);
 }

@@ -80,22 +80,25 @@ BPM_DEV void flush_colsum_wide(const Prob& P, f32x4 cs, int nb, int lane) {
 // side operands of rows mrow + 4 * i (i < NI), columns nb .. nb + 3: requested one 16-row step ahead of their use (the
 // epilogue of a wave tile is a chain of TMW such steps, each a ~2 us round trip to memory when the loads sit right before
 // the arithmetic: 10 steps at 160 rows per wave cost as much as the 12-stage main loop of a K = 768 product)
-template <int NI>
+// OT: element type of CT outputs and of the gate operand (bf16; float for the bf16x3 products, whose activations are f32)
+template <int NI, typename OT = bf16_t>
 struct WideSide {
+    typedef typename std::conditional<sizeof(OT) == 4, f32x4, bf16x4>::type gate_t;
     f32x4 addv[NI];
-    bf16x4 gt[NI];
+    gate_t gt[NI];
 };
 
-template <int NI>
-BPM_DEV void wide_load(const Prob& P, int mrow, int nb, WideSide<NI>& s) {
+template <int NI, typename OT = bf16_t>
+BPM_DEV void wide_load(const Prob& P, int mrow, int nb, WideSide<NI, OT>& s) {
+    typedef typename WideSide<NI, OT>::gate_t gate_t;
     const uint32_t nbc = nb < P.N ? (uint32_t)nb : 0u;
     const bool accum = P.out_kind == BPM_OUT_F32 && (P.flags & BPM_GEMM_ACCUM);
     if (P.gate) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) s.gt[i] = *(const bf16x4*)((const bf16_t*)P.gate + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldg + nbc);
+        for (int i = 0; i < NI; ++i) s.gt[i] = *(const gate_t*)((const OT*)P.gate + (uint32_t)min(mrow + 4 * i, P.M - 1) * (uint32_t)P.ldg + nbc);
     } else {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) s.gt[i] = bf16x4{};
+        for (int i = 0; i < NI; ++i) s.gt[i] = gate_t{};
     }
     if (P.resid) {
 #pragma unroll
@@ -110,8 +113,8 @@ BPM_DEV void wide_load(const Prob& P, int mrow, int nb, WideSide<NI>& s) {
 }
 
 // rows mrow + 4 * i (i < NI), columns nb .. nb + 3
-template <int NI>
-BPM_DEV void wide_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NI], const f32x4 bias, const WideSide<NI>& s, f32x4& csum) {
+template <int NI, typename OT = bf16_t>
+BPM_DEV void wide_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NI], const f32x4 bias, const WideSide<NI, OT>& s, f32x4& csum) {
     const bool colok = nb < P.N;
     const bool f32out = P.out_kind == BPM_OUT_F32;
 #pragma unroll
@@ -143,20 +146,20 @@ BPM_DEV void wide_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, co
         } else if (P.out_kind == BPM_OUT_CT) {
             if (e.ok && nb < P.ldc) {                   // pad columns [N, ldc) receive zeros
                 if (!valid) x = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3];
-                *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o;
+                if constexpr (sizeof(OT) == 4) *(f32x4*)((float*)P.C + e.offc + nb) = x;
+                else { bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3]; *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o; }
             }
         } else if (valid) {                             // head-major
             uint32_t h = (uint32_t)nb / (uint32_t)P.hdh, c = (uint32_t)nb - h * (uint32_t)P.hdh;
             const uint32_t hstride = (uint32_t)(P.hT * P.hdhp);
-            bf16_t* base = (bf16_t*)P.C + e.hrow;
+            OT* base = (OT*)P.C + e.hrow;
             if ((P.hdh & 3) == 0) {                     // the 4 columns stay inside one head
-                bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3];
-                *(bf16x4*)(base + h * hstride + c) = o;
+                if constexpr (sizeof(OT) == 4) *(f32x4*)(base + h * hstride + c) = x;
+                else { bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3]; *(bf16x4*)(base + h * hstride + c) = o; }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    base[h * hstride + c] = (bf16_t)x[q];
+                    base[h * hstride + c] = (OT)x[q];
                     if (++c == (uint32_t)P.hdh) { c = 0; ++h; }
                 }
             }
@@ -240,8 +243,13 @@ BPM_DEV void dma_issue_part(__amdgpu_buffer_rsrc_t rsx, __amdgpu_buffer_rsrc_t r
 // WMD x WND waves, each a (16 TMW) x 64 block of the (16 TMW WMD) x (64 WND) workgroup tile; NS LDS stages.
 // XS: some problem of the launch wants the column sums of X (bias gradient beside a weight gradient, TN only); without
 // them the 8 / 4 extra accumulators are not carried (they spilled the 128 x 64 wave tile past its 256 registers).
-template <bool XK, bool YK, int WMD, int WND, int TMW, int NS, bool XS = false>
+// X3: the operands are split-bf16 images [rows, hi plane | lo plane] of fp32 matrices (bpm_split_rows; the leading
+// dimension spans both planes, so a plane is ld / 2 elements = ld BYTES further) and the product is
+// x y ~ hi hi + hi lo + lo hi: the k loop runs three segments of ceil(K / 64) stages over plane pairs (hi, hi), (hi, lo),
+// (lo, hi) into the same accumulators; CT outputs and the gate operand are fp32.  Everything else is the same kernel.
+template <bool XK, bool YK, int WMD, int WND, int TMW, int NS, bool XS = false, bool X3 = false>
 __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group grp) {
+    typedef typename std::conditional<X3, float, bf16_t>::type OT;
     static_assert(!XS || (!XK && !YK), "column sums of X belong to the weight-gradient product");
     constexpr int NW = WMD * WND, BMD = 16 * TMW * WMD, BND = 64 * WND, WROWS = 16 * TMW;
     typedef DmaSide<XK, BMD, NW> SX;
@@ -261,19 +269,26 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     const Prob& P = pick_problem(grp, bid);
     if (BPM_BASE_PRIO && XK && !(P.flags & BPM_GEMM_BACKGROUND)) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     const int m0 = (bid / P.tiles_n) * BMD, n0 = (bid % P.tiles_n) * BND;
-    const int nkt = (P.K + DK - 1) / DK;
+    const int nk1 = (P.K + DK - 1) / DK;                  // stages per plane pair
+    const int nkt = X3 ? 3 * nk1 : nk1;
 
     // descriptor = exactly the bytes the operand owns: (rows - 1) leading dimensions plus the last row's width (whole k
     // stages of a k-contiguous row, whole 16-byte chunks of a k-strided one) -- an operand that is a COLUMN VIEW of a wider
     // buffer then never reads past the parent's last row (rows * ld from the view's first element would)
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, desc_bytes(XK ? P.M : P.K, P.ldx, XK ? nkt * DK : (P.M + 7) & ~7, 2, (P.flags & BPM_GEMM_A_OVERLAP) != 0), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, desc_bytes(YK ? P.N : P.K, P.ldy, YK ? nkt * DK : (P.N + 7) & ~7, 2, (P.flags & BPM_GEMM_B_OVERLAP) != 0), 0x00020000);
+    // (X3: a split image is a whole allocation of rows x ld elements with zero pad columns in both planes: the range check
+    // only has to cut off rows past M / N and k-rows past K)
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, X3 ? (XK ? P.M : P.K) * P.ldx * 2 : desc_bytes(XK ? P.M : P.K, P.ldx, XK ? nkt * DK : (P.M + 7) & ~7, 2, (P.flags & BPM_GEMM_A_OVERLAP) != 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, X3 ? (YK ? P.N : P.K) * P.ldy * 2 : desc_bytes(YK ? P.N : P.K, P.ldy, YK ? nkt * DK : (P.N + 7) & ~7, 2, (P.flags & BPM_GEMM_B_OVERLAP) != 0), 0x00020000);
     const int vx = SX::voffset(P.ldx, m0, wave, lane), vy = SY::voffset(P.ldy, n0, wave, lane);
     const int stepx = SX::stage_step(P.ldx), stepy = SY::stage_step(P.ldy);
     const int ldx = P.ldx, ldy = P.ldy;
 
+    // byte offsets of stage kt: its k position, and (X3) the planes of its segment -- (hi, hi), (hi, lo), (lo, hi)
+    auto seg_of = [&](int kt) { return !X3 ? 0 : (kt >= 2 * nk1 ? 2 : (kt >= nk1 ? 1 : 0)); };
     auto part = [&](int kt, int buf, auto Q) {
-        dma_issue_part<SX, SY, decltype(Q)::value>(rsx, rsy, smem + buf * STAGE, vx, vy, kt * stepx, kt * stepy, ldx, ldy, wave);
+        const int seg = seg_of(kt), kk = kt - seg * nk1;
+        dma_issue_part<SX, SY, decltype(Q)::value>(rsx, rsy, smem + buf * STAGE, vx, vy, kk * stepx + (seg == 2 ? ldx : 0),
+                                                   kk * stepy + (seg == 1 ? ldy : 0), ldx, ldy, wave);
     };
     auto stage = [&](int kt, int buf) {
         part(kt, buf, std::integral_constant<int, 0>{}); part(kt, buf, std::integral_constant<int, 1>{});
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
 #pragma unroll
             for (int a = 0; a < 4; ++a) fy[a] = SY::frag(iy, wn * 64 + 16 * a, ks, lane);
             if constexpr (XS) {
-                if (do_xs) {
+                if (do_xs && seg_of(kt) != 1) {            // (X3: segments 0 and 2 carry X's hi and lo planes; segment 1 repeats hi)
                     bf16x8 one;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) one[j] = (bf16_t)1.0f;
@@ -390,10 +405,10 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     // side operands of 16-row step h live in sd[h % (AH + 1)], requested AH steps before their use -- where the register
     // budget allows: the 16-wave configuration (128 registers) spills with two sets and requests them right before their use
     constexpr int AH = NW < 16 ? BPM_EPI_AHEAD : 0;
-    WideSide<4> sd[AH + 1];
+    WideSide<4, OT> sd[AH + 1];
 #pragma unroll
     for (int h0 = 0; h0 < AH; ++h0)
-        if (h0 < TMW) wide_load<4>(P, mw + 16 * h0 + lr, nbw, sd[h0]);
+        if (h0 < TMW) wide_load<4, OT>(P, mw + 16 * h0 + lr, nbw, sd[h0]);
     auto pass = [&](auto PB) {             // rows 32 PB .. 32 PB + 31 of the wave tile
         constexpr int pb = decltype(PB)::value;
         if constexpr (pb < TMW / 2) {
@@ -407,14 +422,14 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {           // 16 rows at a time: 4 row steps per lane in flight
                 const int h = 2 * pb + hf;
-                if (h + AH < TMW || AH == 0) wide_load<4>(P, mw + 16 * (h + AH) + lr, nbw, sd[(h + AH) % (AH + 1)]);
+                if (h + AH < TMW || AH == 0) wide_load<4, OT>(P, mw + 16 * (h + AH) + lr, nbw, sd[(h + AH) % (AH + 1)]);
                 f32x4 v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 16 * hf + 4 * i + lr;
                     v[i] = *(const f32x4*)(blk + row * 256 + ((lc ^ (row & 15)) << 4));
                 }
-                wide_apply<4>(P, drop, mw + 16 * h + lr, nbw, v, bias, sd[h % (AH + 1)], cs);
+                wide_apply<4, OT>(P, drop, mw + 16 * h + lr, nbw, v, bias, sd[h % (AH + 1)], cs);
             }
         }
     };

@@ -775,6 +775,38 @@ __global__ __launch_bounds__(NT) void add_n_kernel(const Grp<AddP> grp) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// split: fp32 [R, C] (row stride ld) -> bf16 [R, 2 ldp]: columns [0, ldp) hold hi = bf16(x), columns [ldp, 2 ldp) hold
+// lo = bf16(x - hi), pad columns [C, ldp) of both planes zero.  Operands of the "bf16x3" products (bpm_gemm_grouped with
+// dtype BPM_BF16X3: x y ~ hi hi + hi lo + lo hi on the bf16 MFMA with f32 accumulation: ~2^-16 relative per product).
+// ---------------------------------------------------------------------------
+struct SplitP { const float* src; bf16_t* dst; int R, C, ld, ldp; };
+
+__global__ __launch_bounds__(NT) void split_rows_kernel(const Grp<SplitP> grp) {
+    unsigned bid = blockIdx.x, nblk;
+    const SplitP& P = pick(grp, bid, nblk);
+    const unsigned cpr = (unsigned)P.ldp >> 2;                     // 4-column chunks per row (ldp % 4 == 0)
+    const size_t total = (size_t)P.R * cpr;
+    const bool vec = ((P.ld & 3) == 0) && ((((uintptr_t)P.src) & 15) == 0);
+    for (size_t i = (size_t)bid * NT + threadIdx.x; i < total; i += (size_t)nblk * NT) {
+        const size_t r = i / cpr;
+        const int c = 4 * (int)(i - r * cpr);
+        f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* sp = P.src + r * P.ld + c;
+        if (vec && c + 3 < P.C) x = *(const f32x4*)sp;
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c + q < P.C) x[q] = sp[q];
+        }
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hi[q] = (bf16_t)x[q]; lo[q] = (bf16_t)(x[q] - (float)hi[q]); }
+        bf16_t* dp = P.dst + r * 2 * (size_t)P.ldp + c;
+        *(bf16x4*)dp = hi;
+        *(bf16x4*)(dp + P.ldp) = lo;
+    }
+}
+
 constexpr unsigned CAP = 2048;   // blocks per problem for grid-stride kernels
 
 template <typename P> inline bool grp_ok(int n) { return n >= 1 && n <= BPM_MAX_GROUP; }
@@ -1194,6 +1226,23 @@ extern "C" int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* q, int n, int d, v
     int rc = fill_gmu(g, q, n, d, true);
     if (rc) return rc;
     BPM_DISPATCH_CT(dtype, gmu2_bwd_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g, d);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int bpm_split_rows(const bpm_split_problem* q, int n, void* stream) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
+    Grp<SplitP> g;
+    g.n = n; g.blk0[0] = 0; g.seedp = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const bpm_split_problem& s = q[i];
+        if (!s.src || !s.dst || s.R < 1 || s.C < 1 || s.ld < s.C || s.ldp < s.C || (s.ldp & 3)) return BPM_ERR_ARG;
+        if (((uintptr_t)s.dst & 7) || ((uintptr_t)s.src & 3)) return BPM_ERR_ALIGN;
+        SplitP& p = g.p[i];
+        p.src = s.src; p.dst = (bf16_t*)s.dst; p.R = s.R; p.C = s.C; p.ld = s.ld; p.ldp = s.ldp;
+        g.blk0[i + 1] = g.blk0[i] + blocks_for((size_t)s.R * (s.ldp >> 2), NT * 4, CAP);
+    }
+    hipLaunchKernelGGL(split_rows_kernel, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
     BPM_CHECK_LAUNCH();
     return 0;
 }

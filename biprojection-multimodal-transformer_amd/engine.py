@@ -89,8 +89,9 @@ class ParamStore:
 
     ALIGN = 64  # elements
 
-    def __init__(self, named_params: Sequence[Tuple[str, torch.nn.Parameter]], dtype: int):
+    def __init__(self, named_params: Sequence[Tuple[str, torch.nn.Parameter]], dtype: int, x3: bool = False):
         self.dtype = dtype
+        self.x3 = bool(x3) and dtype != BPM_BF16      # bf16x3 mode: fp32 storage, large GEMMs as three split-bf16 products
         self.side_low = True                            # side-stream priority: set by the plan that launches over this store
         self.names = [n for n, _ in named_params]
         self.params = {n: p for n, p in named_params}
@@ -122,6 +123,14 @@ class ParamStore:
         self.shadow_flat: Optional[torch.Tensor] = None
         self._table = None
         self._master_ptr = self.master.data_ptr()
+
+    def __del__(self):
+        r = getattr(self, "_x3_range", None)
+        if r is not None:
+            try:
+                ops.x3_drop_static(*r)
+            except Exception:              # noqa: BLE001 -- interpreter shutdown
+                pass
 
     # -- masters / grads ------------------------------------------------------
     def p(self, name: str) -> torch.Tensor:
@@ -239,6 +248,9 @@ class ParamStore:
             d.colscale = self.params[colscale].data_ptr() if colscale else None
             blk += (rows * ld + 1023) // 1024
             descs.append(d)
+        if self.x3:                                    # the weight shadows are the static operands of the bf16x3 products
+            self._x3_range = (self.shadow_flat.data_ptr(), self.shadow_flat.data_ptr() + self.shadow_flat.numel() * esz)
+            ops.x3_register_static(*self._x3_range)
         self._ndesc, self._nblk = len(descs), blk
         if descs:
             arr = (PackDesc * len(descs))(*descs)
@@ -366,6 +378,8 @@ class ParamStore:
             ops.pack_weights(self.dtype, *self._rest_table)
         if self._fold_table is not None:
             ops.fold_bias(self._fold_table, self._nfold, self._fold_blk)
+        if self.x3:
+            ops.x3_refresh_static()                # split images of the shadows that just changed (outside any graph)
 
 
 # ----------------------------------------------------------------------------
@@ -596,7 +610,9 @@ class EncoderGroupPlan:
         # critical-path issue priority (16.79 -> 16.73 ms/step): the forward ones gate the next attention
         for p in probs:
             p.flags |= F_KPAD | (F_BACKGROUND if background else 0)
-        return (ops.gemm_grouped, self.dtype, variant, ops.array(GemmProblem, probs))
+        arr = ops.array(GemmProblem, probs)
+        arr.x3 = self.store.x3                       # bf16x3 mode: ops.gemm_grouped splits the operands of eligible launches
+        return (ops.gemm_grouped, self.dtype, variant, arr)
 
     # -- forward tables ---------------------------------------------------------
     def _build_fwd(self, training: bool):

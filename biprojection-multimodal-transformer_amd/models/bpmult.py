@@ -235,7 +235,7 @@ class _Trunk:
             ops.pack_rows_fwd(BPM_F32, packs_f32, seed)
         if packs_ct:
             ops.pack_rows_fwd(self.dtype, packs_ct, seed)
-            ops.gemm_grouped(self.dtype, GEMM_NT, gemms, seed)
+            ops.gemm_grouped(self.dtype, GEMM_NT, gemms, seed, x3=st.x3)
 
     def conv_backward(self, seed: int, need_dx: Dict[str, bool]) -> Dict[str, Optional[torch.Tensor]]:
         """Consumes dpx[m]; accumulates proj_m.weight gradients; returns d(feats[m]) where requested."""
@@ -260,9 +260,9 @@ class _Trunk:
                 unpack.append(ops.pack_problem(B, T, od, 0, g=c["dpk"], ldg=od, dsrc=res[k], drop_p=c["p"], drop_site=SITE_TEXT))
         if casts:
             ops.rows_cast(self.dtype, casts, seed)
-            ops.gemm_grouped(self.dtype, GEMM_TN, wg, seed)
+            ops.gemm_grouped(self.dtype, GEMM_TN, wg, seed, x3=st.x3)
         if dg:
-            ops.gemm_grouped(self.dtype, GEMM_NN, dg, seed)
+            ops.gemm_grouped(self.dtype, GEMM_NN, dg, seed, x3=st.x3)
         if unpack:
             ops.pack_rows_bwd(unpack, seed)
         return res
@@ -358,6 +358,8 @@ class _Trunk:
                            ops.gemm_problem(g["dag"], st.sptr(wg_, ld), g["dx2"], R, d, d, ld, 2 * ld, d, flags=F_ACCUM)]
         self._gmu_fwd = (A(CastProblem, casts), A(GemmProblem, gemms), A(GmuProblem, gates))
         self._gmu_bwd = (A(GmuProblem, bw_gate), A(GemmProblem, bw_wg), A(GemmProblem, bw_dg), A(GemmProblem, bw_dg2))
+        for arr in (self._gmu_fwd[1],) + self._gmu_bwd[1:]:
+            arr.x3 = st.x3                       # bf16x3 mode: eligible launches run as three split-bf16 products
 
     def gmu_forward(self) -> None:
         casts, gemms, gates = self._gmu_fwd
@@ -860,8 +862,9 @@ class _BPMulTBase(nn.Module):
                 bounds.append((sname, len(named), len(named) + len(part)))
                 named += part
             assert len(named) == len(allp), "every trunk parameter belongs to exactly one section"
-            dt = config.dtype_code(self.precision or config.precision())
-            st = ParamStore(named, dt)
+            prec = self.precision or config.precision()
+            dt = config.dtype_code(prec)
+            st = ParamStore(named, dt, x3=config.is_x3(prec))
             st.sections = {}
             for sname, a, b in bounds:
                 lo = st.off[named[a][0]] if b > a else 0

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (BPM_BF16, BPM_F32, F_ACCUM, F_ATOMIC, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, GEMM_MAX_GROUP, MAX_GROUP, OUT_CT,
+from ._lib import (BPM_BF16, BPM_BF16X3, BPM_F32, F_ACCUM, F_ATOMIC, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, GEMM_MAX_GROUP, MAX_GROUP, OUT_CT,
                    OUT_F32, OUT_HEADS, AttnProblem, CastProblem, EmbedProblem, GemmProblem, GmuProblem,
                    LnProblem, PackProblem)
 
@@ -107,11 +107,126 @@ def gemm_problem(A, B, Cc, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
     return p
 
 
-def gemm_grouped(dtype: int, variant: int, probs, seed: int = 0, n: Optional[int] = None) -> None:
+def gemm_grouped(dtype: int, variant: int, probs, seed: int = 0, n: Optional[int] = None, x3: bool = False) -> None:
+    """x3 (or an array tagged `.x3 = True` where the launch tables are built): the parity-grade fast mode -- fp32 operands,
+    each product as three bf16 MFMA products of split operands (see _X3Plan); launches the LDS-DMA kernel cannot take
+    run as exact fp32 products."""
     arr = _as_array(GemmProblem, probs)
     L, s = _lib.lib(), _stream()
+    if (x3 or getattr(arr, "x3", False)) and dtype == BPM_F32 and variant in _X3_VARIANTS:
+        plan = getattr(arr, "_x3_plan", None)
+        if plan is None or plan.n != n:
+            plan = _X3Plan(arr, variant, n)
+            arr._x3_plan = plan              # tables are replayed every step; lists were turned into a fresh array above
+        if plan.ok:
+            plan.run(L, variant, _seed(seed), s)
+            return
     for sub, k in _chunks(arr, GemmProblem, n, GEMM_MAX_GROUP):
         _lib.check(L.bpm_gemm_grouped(dtype, variant, sub, k, _seed(seed), s), "bpm_gemm_grouped")
+
+
+# ---- bf16x3: fp32 products as three bf16 MFMA products of split operands -------------------------------------------
+# x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); x y ~ hi hi + hi lo + lo hi with f32 accumulation: ~2^-16 relative per
+# product (the lo lo term and the rounding of lo), against 2^-9 for plain bf16 operands.  Every operand of an eligible
+# launch is split by bpm_split_rows into a [rows, hi plane | lo plane] bf16 image (cached per operand view: the buffers
+# of the hot path are static) right before the launch; weight shadows -- operands inside a registered static range -- are
+# split again only after the shadows were refreshed.
+# lab knob: BPMULT_X3_ONLY=nt,nn restricts the split path to those operand arrangements (bisecting a parity failure)
+_X3_VARIANTS = {{"nt": GEMM_NT, "nn": GEMM_NN, "tn": GEMM_TN}[v] for v in __import__("os").environ.get("BPMULT_X3_ONLY", "nt,nn,tn").split(",") if v}
+_X3_BUFFERS = {}                # (ptr, rows, cols, ld) -> split image
+_X3_STATIC = []                 # [lo, hi) address ranges of operands that only change at a refresh (weight shadows)
+_X3_STATIC_SPLITS = {}          # (ptr, rows, cols, ld) -> SplitProblem of every static operand seen so far
+
+
+def x3_drop_static(lo: int, hi: int) -> None:
+    """A parameter store is gone (its model was moved or deleted): forget its static operands -- their addresses are."""
+    if (lo, hi) in _X3_STATIC:
+        _X3_STATIC.remove((lo, hi))
+    for k in [k for k in _X3_STATIC_SPLITS if lo <= k[0] < hi]:
+        del _X3_STATIC_SPLITS[k]
+
+
+def x3_register_static(lo: int, hi: int) -> None:
+    if (lo, hi) not in _X3_STATIC:
+        _X3_STATIC.append((lo, hi))
+
+
+def _split(L, probs, s) -> None:
+    arr = _as_array(_lib.SplitProblem, probs)
+    for sub, k in _chunks(arr, _lib.SplitProblem, None):
+        _lib.check(L.bpm_split_rows(sub, k, s), "bpm_split_rows")
+
+
+def x3_refresh_static() -> None:
+    """Split every static operand again (ParamStore.refresh_shadows, after the weight shadows changed).  A host-side
+    decision, outside any captured graph -- like the shadow refresh itself; the launch plans never split static operands
+    except the first time they meet one."""
+    if _X3_STATIC_SPLITS:
+        _split(_lib.lib(), list(_X3_STATIC_SPLITS.values()), _stream())
+
+
+class _X3Plan:
+    """Split problems + the BPM_BF16X3 problem table of one grouped GEMM launch (built once per launch table)."""
+
+    def __init__(self, arr, variant: int, n: Optional[int]):
+        self.n = n
+        cnt = len(arr) if n is None else n
+        P = [arr[i] for i in range(cnt)]
+        xk, yk = variant != GEMM_TN, variant == GEMM_NT
+        self.ok = all(self._eligible(p) for p in P) and cnt <= GEMM_MAX_GROUP
+        if self.ok and variant == GEMM_TN:            # one 256 x 256 tile per CU must roughly fill the chip (as in bf16 mode)
+            self.ok = sum(((p.M + 255) // 256) * ((p.N + 255) // 256) for p in P) * 8 >= 256 * 3
+        if not self.ok:
+            return
+        dyn, new_static, out = [], [], []
+        seen = {}
+        for p in P:
+            q = GemmProblem()
+            C.memmove(C.byref(q), C.byref(p), C.sizeof(GemmProblem))
+            for side, rows, cols, ld in (("A", p.M if xk else p.K, p.K if xk else p.M, p.lda),
+                                         ("B", p.N if yk else p.K, p.K if yk else p.N, p.ldb)):
+                ptr = getattr(p, side)
+                key = (ptr, rows, cols, ld)
+                ldp = (cols + 127) // 128 * 128
+                buf = _X3_BUFFERS.get(key)
+                if buf is None:
+                    # torch.empty, NOT zeros: bpm_split_rows writes every column of both planes (pads included), and an
+                    # initialising kernel on the allocating stream would race with the other stream's split of the same
+                    # operand (main runs ahead of the side stream: its split + product would be wiped by the late fill)
+                    buf = _X3_BUFFERS[key] = torch.empty(rows, 2 * ldp, device="cuda", dtype=torch.bfloat16)
+                if key not in seen:
+                    seen[key] = True
+                    sp = _lib.SplitProblem()
+                    sp.src, sp.dst, sp.R, sp.C, sp.ld, sp.ldp = ptr, buf.data_ptr(), rows, cols, ld, ldp
+                    if any(lo <= ptr < hi for lo, hi in _X3_STATIC):
+                        if key not in _X3_STATIC_SPLITS:
+                            _X3_STATIC_SPLITS[key] = sp
+                            new_static.append(sp)
+                    else:
+                        dyn.append(sp)
+                setattr(q, side, buf.data_ptr())
+                setattr(q, "lda" if side == "A" else "ldb", 2 * ldp)
+            q.flags |= F_KPAD
+            out.append(q)
+        self.gemm = array(GemmProblem, out)
+        self.dyn = array(_lib.SplitProblem, dyn) if dyn else None
+        if new_static:                                # first sight of a weight shadow: split it now (plans are built by eager
+            _split(_lib.lib(), new_static, _stream())  # launches, never inside a graph capture); later: x3_refresh_static()
+
+    @staticmethod
+    def _eligible(p) -> bool:
+        al = (p.bias_n or 0) | (p.resid or 0) | (p.C or 0) | (p.gate or 0)
+        tm, tn = (p.M + 255) // 256, (p.N + 255) // 256
+        return (p.M >= 256 and p.N >= 256 and p.K >= 256 and p.N % 4 == 0 and al % 16 == 0 and (p.ldr | p.ldc | p.ldg) % 4 == 0
+                and not p.bias_m and p.splitk <= 1 and not (p.flags & (F_ATOMIC | _lib.F_A_OVERLAP | _lib.F_B_OVERLAP))
+                and not (p.resid and (p.flags & F_ACCUM)) and p.M * p.N >= 0.8 * (tm * 256) * (tn * 256)
+                and p.lda % 4 == 0 and p.ldb % 4 == 0 and (p.A or 0) % 16 == 0 and (p.B or 0) % 16 == 0)
+
+    def run(self, L, variant: int, seed: int, s: int) -> None:
+        if self.dyn is not None:
+            for sub, k in _chunks(self.dyn, _lib.SplitProblem, None):
+                _lib.check(L.bpm_split_rows(sub, k, s), "bpm_split_rows")
+        _lib.check(L.bpm_gemm_grouped(_lib.BPM_BF16X3, variant, self.gemm, len(self.gemm), seed, s), "bpm_gemm_grouped(bf16x3)")
 
 
 # ----------------------------------------------------------------------------

@@ -42,7 +42,8 @@ extern "C" {
 #define BPM_MAX_GROUP 18 /* problems per grouped launch (6 encoders of a level x 3 projections) */
 #define BPM_GEMM_MAX_GROUP 24 /* bpm_gemm_grouped alone: 6 encoders x (q, k, v, out) weight gradients in one launch */
 
-enum { BPM_F32 = 0, BPM_BF16 = 1 };
+enum { BPM_F32 = 0, BPM_BF16 = 1,
+       BPM_BF16X3 = 2 /* bpm_gemm_grouped only: split-bf16 operands (bpm_split_rows), three bf16 MFMA products per fp32 product */ };
 enum { BPM_ERR_ARG = -1, BPM_ERR_ALIGN = -2 };
 
 int bpm_version(void);
@@ -276,6 +277,16 @@ typedef struct bpm_cast_problem {
     float drop_p; uint32_t drop_site;
 } bpm_cast_problem;
 int bpm_rows_cast(int dtype, const bpm_cast_problem* probs, int n, uint64_t seed, void* stream);
+
+/* fp32 [R, C] (row stride ld) -> split bf16 [R, 2 ldp] for the BPM_BF16X3 products: columns [0, ldp) = hi = bf16(x),
+ * columns [ldp, 2 ldp) = lo = bf16(x - hi), pad columns [C, ldp) of both planes zero (ldp % 4 == 0; the LDS-DMA GEMM
+ * wants ldp % 128 == 0).  The parity-grade mode of the linear layers (multihead_attention.py:152-158,
+ * transformer.py:186-190, F.linear everywhere on the path): x y ~ hi hi + hi lo + lo hi, f32 accumulation. */
+typedef struct bpm_split_problem {
+    const float* src; void* dst;
+    int R, C, ld, ldp;
+} bpm_split_problem;
+int bpm_split_rows(const bpm_split_problem* probs, int n, void* stream);
 
 /* Fusion-GMU gating (GatedMultimodalLayerFeatures.forward, mmtr.py:189-195):
  * out = z*tanh(a1)*x1 + (1-z)*tanh(a2)*x2, z = sigmoid(ag); a1,a2,ag fp32 [R,d]

@@ -958,3 +958,99 @@ def test_audio_encoder_frontend_against_torch_and_reference_fixture(prec):
     close(x.grad, xr.grad, t_g, "d(audio)")
     for (k, p), r in zip(enc.named_parameters(), ref_leaves):
         close(p.grad, r.grad, t_g, "d(" + k + ")")
+
+
+@pytest.mark.parametrize("variant,M,N,K", [(GEMM_NT, 1024, 768, 768), (GEMM_NT, 1000, 3072, 768), (GEMM_NN, 1024, 768, 3072),
+                                          (GEMM_NN, 900, 1024, 1000), (GEMM_TN, 768, 3072, 4096), (GEMM_TN, 768, 768, 1000)])
+def test_gemm_bf16x3_products(variant, M, N, K):
+    """The parity-grade fast products (ops.gemm_grouped(..., x3=True) on fp32 operands: bpm_split_rows + BPM_BF16X3 on the
+    LDS-DMA kernel, x y ~ hi hi + hi lo + lo hi) against fp64 on the SAME fp32 operands: <= 5e-5 of the result's scale
+    (plain bf16 operands: ~4e-3), with the fused epilogues the encoder uses -- bias + residual + dropout -> f32,
+    relu -> fp32 CT, bias gradient beside a weight gradient (column sums of X), += -- and ragged M / K."""
+    from bpmult_amd.ops import F_KPAD
+    g = torch.Generator().manual_seed(31)
+    dev = DEV
+    if variant == GEMM_NT:
+        A, Bm = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+        ref = A.double() @ Bm.double().T
+    elif variant == GEMM_NN:
+        A, Bm = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=K ** -0.5)
+        ref = A.double() @ Bm.double()
+    else:
+        A, Bm = rnd(K, M, seed=1), rnd(K, N, seed=2, scale=K ** -0.5)
+        ref = A.double().T @ Bm.double()
+    pad = lambda t: torch.nn.functional.pad(t, (0, pad32(t.shape[1]) - t.shape[1])).contiguous().to(dev)
+    Ad, Bd = pad(A), pad(Bm)
+    scale = float(ref.abs().max())
+    # plain store
+    out = torch.full((M, N), float("nan"), device=dev)
+    p = ops.gemm_problem(Ad, Bd, out, M, N, K, Ad.shape[1], Bd.shape[1], N, flags=F_KPAD)
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    arr = ops.array(ops.GemmProblem, [p] * max(3, -(-100 // tiles)))      # (a weight-gradient launch takes the split path when it fills ~a third of the chip)
+    ops.gemm_grouped(BPM_F32, variant, arr, x3=True)
+    assert arr._x3_plan.ok, "this launch must take the split-bf16 path, not the exact fp32 fallback"
+    e3 = float((out.cpu().double() - ref).abs().max()) / scale
+    assert e3 <= 5e-5, f"bf16x3 max err / scale = {e3:.2e}"
+    # exact f32 kernel on the same operands: the x3 product must be within a few 1e-5 of it too
+    out32 = torch.zeros(M, N, device=dev)
+    ops.gemm_grouped(BPM_F32, variant, [ops.gemm_problem(Ad, Bd, out32, M, N, K, Ad.shape[1], Bd.shape[1], N, flags=F_KPAD)])
+    assert float((out - out32).abs().max()) / scale <= 5e-5
+    if variant == GEMM_TN:                      # weight gradient: += and the bias gradient (column sums of X) beside it
+        base = rnd(M, N, seed=5).to(dev)
+        acc = base.clone()
+        cs = torch.zeros(M, device=dev)
+        scratch = [torch.zeros(M, N, device=dev) for _ in range(2)]
+        ops.gemm_grouped(BPM_F32, variant, [ops.gemm_problem(Ad, Bd, acc, M, N, K, Ad.shape[1], Bd.shape[1], N, flags=F_KPAD | F_ACCUM,
+                                                            colsum_a=cs)] +
+                         [ops.gemm_problem(Ad, Bd, scratch[i % 2], M, N, K, Ad.shape[1], Bd.shape[1], N, flags=F_KPAD)
+                          for i in range(max(2, -(-100 // tiles)))], x3=True)
+        close(acc, ref + base.cpu().double(), 5e-5, "accumulate")
+        close(cs, A.double().sum(0), 5e-5, "colsum_a")
+    else:                                       # forward / data-gradient epilogues
+        bias, resid = rnd(N, seed=6).to(dev), rnd(M, N, seed=7).to(dev)
+        o1 = torch.full((M, N), float("nan"), device=dev)
+        o2 = torch.full((M, pad32(N)), float("nan"), device=dev)
+        ps = [ops.gemm_problem(Ad, Bd, o1, M, N, K, Ad.shape[1], Bd.shape[1], N, bias_n=bias, resid=resid, ldr=N, drop_p=0.25, drop_site=9, flags=F_KPAD),
+              ops.gemm_problem(Ad, Bd, o2, M, N, K, Ad.shape[1], Bd.shape[1], pad32(N), bias_n=bias, flags=F_KPAD | F_RELU, out_kind=OUT_CT)]
+        ops.gemm_grouped(BPM_F32, variant, ps, seed=77, x3=True)
+        dm = drop_mult((M, N), 0.25, 77, 9).double()
+        close(o1, (ref + bias.cpu().double()) * dm + resid.cpu().double(), 5e-5 * 2, "bias + dropout + residual")
+        close(o2[:, :N], (ref + bias.cpu().double()).clamp_min(0), 5e-5, "relu -> CT (fp32)")
+        assert float(o2[:, N:].abs().max()) == 0.0 if pad32(N) > N else True
+
+
+@pytest.mark.parametrize("variant", [GEMM_NT, GEMM_NN, GEMM_TN])
+def test_gemm_bf16x3_at_the_model_launch_shapes(variant):
+    """The bf16x3 products at the launch shapes of the headline model (hidden 768, six problems of 4096 rows: the 320 x 256
+    tile configuration for N = 768 products; 24 weight gradients of 768 x 768 x 4096 with their bias column sums in one
+    launch) -- every problem of the launch against fp64 on the same fp32 operands."""
+    from bpmult_amd.ops import F_KPAD
+    dev = DEV
+    if variant == GEMM_TN:
+        G, M, N, K = 24, 768, 768, 4096
+    else:
+        G, M, N, K = 6, 4096, 768, 3072
+    probs, refs, outs, sums, keep = [], [], [], [], []
+    for gi in range(G):
+        if variant == GEMM_NT:
+            A, Bm = rnd(M, K, seed=100 + gi), rnd(N, K, seed=200 + gi, scale=K ** -0.5)
+            ref = A.double() @ Bm.double().T
+        elif variant == GEMM_NN:
+            A, Bm = rnd(M, K, seed=100 + gi), rnd(K, N, seed=200 + gi, scale=K ** -0.5)
+            ref = A.double() @ Bm.double()
+        else:
+            A, Bm = rnd(K, M, seed=100 + gi), rnd(K, N, seed=200 + gi, scale=K ** -0.5)
+            ref = A.double().T @ Bm.double()
+        Ad, Bd = A.to(dev), Bm.to(dev)
+        out = torch.full((M, N), float("nan"), device=dev)
+        cs = torch.zeros(M, device=dev) if variant == GEMM_TN else None
+        probs.append(ops.gemm_problem(Ad, Bd, out, M, N, K, Ad.shape[1], Bd.shape[1], N, flags=F_KPAD, colsum_a=cs))
+        refs.append(ref); outs.append(out); sums.append((cs, A.double().sum(0) if cs is not None else None)); keep += [Ad, Bd]
+    arr = ops.array(ops.GemmProblem, probs)
+    ops.gemm_grouped(BPM_F32, variant, arr, x3=True)
+    assert arr._x3_plan.ok
+    torch.cuda.synchronize()
+    for gi in range(G):
+        close(outs[gi], refs[gi], 5e-5, f"problem {gi}")
+        if sums[gi][0] is not None:
+            close(sums[gi][0], sums[gi][1], 5e-5, f"column sums of X, problem {gi}")

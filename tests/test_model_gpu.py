@@ -55,9 +55,17 @@ BF16_FWD, BF16_GRAD, BF16_GRAD_TOY = 2.5e-2, 3e-1, 4e-1
 BF16_GNORM_BIG = 5e-2
 
 
+# bf16x3 mode (fp32 storage, the large linear-layer products as three split-bf16 MFMA products): the north star's bar --
+# logits / gates / loss within 1e-3 of the reference (measured ~1e-5: profiles/r04_parity_errors.json), gradients 5e-3
+X3_FWD, X3_GRAD = 1e-3, 5e-3
+
+
 def check(a, b, prec, what, f32_rel=2e-3, f32_abs=None, bf16_rel=BF16_FWD):
     e, scale, rel = err(a, b)
-    if prec == "f32":
+    if prec == "bf16x3":
+        lim = (X3_FWD if f32_abs is not None else X3_GRAD) * max(scale, 1e-3)
+        assert e <= lim, f"{what}: max err {e:.3e} > {lim:.3e} (scale {scale:.3g})"
+    elif prec == "f32":
         lim = f32_abs if f32_abs is not None else f32_rel * max(scale, 1e-3)
         assert e <= lim, f"{what}: max err {e:.3e} > {lim:.3e} (scale {scale:.3g})"
     else:
@@ -137,7 +145,7 @@ def run_model(g, model, pfx, inputs, call, prec, BF16_GRAD=BF16_GRAD_TOY, BF16_G
         gn = g["gn." + k]
         n = p.grad.double().norm().item()
         rel = abs(n - gn[0]) / max(gn[0], 1e-9)
-        assert rel <= (5e-3 if prec == "f32" else BF16_GNORM), f"grad norm of {k}: {n:.6e} vs reference {gn[0]:.6e}"
+        assert rel <= (5e-3 if prec in ("f32", "bf16x3") else BF16_GNORM), f"grad norm of {k}: {n:.6e} vs reference {gn[0]:.6e}"
         if "g." + k in g:
             check(p.grad, g["g." + k], prec, "grad " + k, bf16_rel=BF16_GRAD)
     for k, t in dev.items():
@@ -171,7 +179,7 @@ def test_f8_mmtrvapt(prec, prune):
 
 
 @pytest.mark.parametrize("prune", SCHEDULES)
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16x3"])
 def test_f9_cfg1_shape(prec, prune):
     """d=300, 12 heads (head_dim 25), 8 layers, lengths padded to 512, B=2."""
     g = load("f9_cfg1")
@@ -183,7 +191,7 @@ def test_f9_cfg1_shape(prec, prune):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "f10_cfg3.npz")), reason="f10 fixture not generated")
 @pytest.mark.parametrize("prune", SCHEDULES)
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16x3"])
 def test_f10_cfg3_shape(prec, prune):
     """BASELINE.json configs[2] dims: 4-modal mmtrvapt, d=768, 6 heads (head_dim 128: the multi-tile attention forward /
     dQ / dK-dV kernels at T=512 / S=200 and 200 / 512), 5 layers, orig_d_v=4096 (K=4096 projection GEMM), biprojection
@@ -206,12 +214,12 @@ def test_f10_cfg3_shape(prec, prune):
     for k in ("xl", "img", "aud"):                      # big inputs: gradient norms only
         n = dev[k].grad.double().norm().item()
         ref = float(g["ginn." + k][0])
-        assert abs(n - ref) <= (5e-3 if prec == "f32" else 1e-1) * ref, (k, n, ref)
+        assert abs(n - ref) <= (5e-3 if prec in ("f32", "bf16x3") else 1e-1) * ref, (k, n, ref)
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "f11_h768.npz")), reason="f11 fixture not generated")
 @pytest.mark.parametrize("prune", SCHEDULES)
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16x3"])
 def test_f11_headline(prec, prune):
     """The bench's headline workload against the reference itself (mmtr.py:587-866): 3-modal mmtrvat, d=768, 12 heads
     (head_dim 64), 8 layers, orig_d 768/35/74, L/V/A = 20/500/400 -> 512, B=1.  Logits, gates, loss, every parameter's
@@ -226,7 +234,7 @@ def test_f11_headline(prec, prune):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "f12_k768.npz")), reason="f12 fixture not generated")
 @pytest.mark.parametrize("prune", SCHEDULES)
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16x3"])
 def test_f12_kernel_point_model(prec, prune):
     """The north-star kernel-point model against the reference itself (BASELINE.json north_star: hidden 768 / seq_len 50;
     bench.py `k768` and `kernel_point`): `mmtrvat` at d=768, 6 heads (head_dim 128), 5 layers, T = S = 50 in all twelve
