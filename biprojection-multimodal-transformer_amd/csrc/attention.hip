@@ -187,7 +187,15 @@ BPM_DEV void store_rows16(char* blk, CT* base, size_t rstride, int nvalid, int d
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: its LDS accesses execute in order; this also pins the compiler
     const bool wide = (dh % EPC) == 0 && (((uintptr_t)base | (uintptr_t)(rstride * SZ)) & 15) == 0;
-    if (wide) {
+    if (wide && dh == DHP) {                                // the usual case (head_dim 64 / 128): row / chunk by shifts, no
+        constexpr int cpr = DHP / EPC, total = 16 * cpr;    // run-time division (that was ~60 VALU instructions per tile)
+#pragma unroll
+        for (int idx0 = 0; idx0 < total; idx0 += 64) {
+            const int idx = idx0 + lane;
+            const int row = idx / cpr, ch = idx % cpr;
+            if (row < nvalid) *(u32x4*)(base + (size_t)row * rstride + ch * EPC) = *(const u32x4*)(blk + row * RS + ch * 16);
+        }
+    } else if (wide) {
         const int cpr = dh / EPC, total = 16 * cpr;
         for (int idx = lane; idx < total; idx += 64) {
             const int row = idx / cpr, ch = idx - row * cpr;
@@ -294,6 +302,10 @@ BPM_DEV void attn_fwd_block(const AProb& P, const DropCfg& drop, char* smem, con
             st[n] = p4;
         }
         const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+        // the probabilities leave each branch already packed as the PV operand (8 registers instead of 16 to merge: without
+        // this the no-dropout path paid 16 v_mov per tile to meet the dropout path's register assignment)
+        constexpr int NPF = KT / Tr<CT>::KSTEP;
+        frag pf[NPF];
         if (dropping) {
             if (pair_ok) {                             // wave-uniform: r = 0..3 share one hash
 #pragma unroll
@@ -308,6 +320,11 @@ BPM_DEV void attn_fwd_block(const AProb& P, const DropCfg& drop, char* smem, con
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st[n][r] *= bpm_drop_mult(drop, drow + (uint32_t)(jb + 16 * n + r));
             }
+#pragma unroll
+            for (int ks = 0; ks < NPF; ++ks) pf[ks] = Tr<CT>::pack_rows(st, ks);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NPF; ++ks) pf[ks] = Tr<CT>::pack_rows(st, ks);
         }
         l_run = l_run * alpha + psum;
 #pragma unroll
@@ -315,22 +332,22 @@ BPM_DEV void attn_fwd_block(const AProb& P, const DropCfg& drop, char* smem, con
         // O^T += V^T Pd^T : k = keys of this tile
         if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
 #pragma unroll
-        for (int ks = 0; ks < KT / Tr<CT>::KSTEP; ++ks) {
-            const frag pf = Tr<CT>::pack_rows(st, ks);
+        for (int ks = 0; ks < NPF; ++ks) {
 #pragma unroll
             for (int n = 0; n < C::ND; ++n)
-                o[n] = Tr<CT>::mma(Tr<CT>::read_tr(vimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf, o[n]);
+                o[n] = Tr<CT>::mma(Tr<CT>::read_tr(vimg, C::STRIDE, ks * Tr<CT>::KSTEP, 16 * n, lane, Tr<CT>::TR_CTILE), pf[ks], o[n]);
         }
         if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     }
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
-    if (q < P.T && g == 0) P.lse[(size_t)bh * P.T + q] = m_run + logf(l_run);
+    // l_run >= 1 (the row maximum contributes exp(0)): v_log_f32 / v_rcp_f32 (1 ulp) without the library's denormal / division fix-ups
+    if (q < P.T && g == 0) P.lse[(size_t)bh * P.T + q] = m_run + __builtin_amdgcn_logf(l_run) * 0.6931471805599453f;
     static_assert(2 * KT * C::STRIDE >= 4 * store_rows16_bytes<CT, DHP>(), "one transpose block per wave in the K / V images");
     __syncthreads();                                   // every wave is done with the K / V images
     if (q0 < P.T)
         store_rows16<CT, DHP>(smem + wave * store_rows16_bytes<CT, DHP>(), (CT*)P.O + ((size_t)q0 * P.B + b) * P.ldo + h * P.dh,
-                              (size_t)P.B * P.ldo, P.T - q0, P.dh, o, 1.f / l_run, lane);
+                              (size_t)P.B * P.ldo, P.T - q0, P.dh, o, __builtin_amdgcn_rcpf(l_run), lane);
 }
 
 // Two 64-row blocks per workgroup, b and nblk - 1 - b: under the future mask block b has b + 1 (forward / dQ) or nblk - b

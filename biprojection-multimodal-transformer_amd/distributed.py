@@ -64,6 +64,11 @@ class GradSync:
         # (event before waiting for the exchange, event after) of the most recent steps: bounded, a long training run
         # must not accumulate live hipEvents
         self._exposed = collections.deque(maxlen=64)
+        # per message of the step in flight: (event when its slice was ready on the communication stream, bytes); finish()
+        # adds the event behind its all-reduce -> `slice_latency_ms` in stats(): how long each slice took from "gradients
+        # final" to "reduced", in issue order (the first real multi-GPU run then shows where the exchange queues up)
+        self._ready = []
+        self._lat = collections.deque(maxlen=16)
         self._bytes = 0
         self._msgs = 0
         self._steps = 0
@@ -77,6 +82,10 @@ class GradSync:
         self._resolve(flat)
         for a in range(lo, hi, self.bucket):
             b = min(hi, a + self.bucket)
+            if flat.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream())
+                self._ready.append((ev, (2 if self.compress == "bf16" else 4) * (b - a)))
             if self.compress == "bf16":
                 half = flat[a:b].to(torch.bfloat16)
                 self._half.append((half, flat[a:b]))
@@ -119,11 +128,17 @@ class GradSync:
             e0.record(main)
         if cuda and self.comm is not None:
             with torch.cuda.stream(self.comm):          # the communication stream waits for RCCL, the main stream for it
+                done = []
                 for h in self.handles:
                     h.wait()
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(self.comm)
+                    done.append(ev)
                 for half, dst in self._half:
                     dst.copy_(half)
             main.wait_stream(self.comm)
+            if len(done) == len(self._ready):
+                self._lat.append([(r, d, n) for (r, n), d in zip(self._ready, done)])
         else:
             for h in self.handles:
                 h.wait()
@@ -131,6 +146,7 @@ class GradSync:
                 dst.copy_(half)
         self._half.clear()
         self.handles.clear()
+        self._ready = []
         inv = 1.0 / self.world
         if tail:
             flat = torch._utils._flatten_dense_tensors(tail)
@@ -152,6 +168,7 @@ class GradSync:
     # -- measurement aid for bench.py ---------------------------------------------
     def reset_stats(self) -> None:
         self._exposed.clear()
+        self._lat.clear()
         self._bytes = 0
         self._msgs = 0
         self._steps = 0
@@ -168,6 +185,12 @@ class GradSync:
             torch.cuda.synchronize()
             ms = [a.elapsed_time(b) for a, b in self._exposed]
             out["exposed_ms_per_step"] = round(sum(ms) / len(ms), 3)
+        if self._lat:
+            torch.cuda.synchronize()
+            steps = [st for st in self._lat if len(st) == len(self._lat[-1])]
+            per = [[r.elapsed_time(d) for r, d, _ in st] for st in steps]
+            out["slice_latency_ms"] = [round(sum(col) / len(col), 3) for col in zip(*per)]     # ready -> reduced, in issue order
+            out["slice_bytes"] = [n for _, _, n in self._lat[-1]]
         return out
 
 

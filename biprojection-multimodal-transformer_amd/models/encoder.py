@@ -116,8 +116,8 @@ class TransformerEncoder(nn.Module):
 
     def _ensure_store(self) -> ParamStore:
         if self._store is None or not self._store.still_flat():
-            dt = config.dtype_code(self.precision or config.precision())
-            self._store = ParamStore(list(self.named_parameters()), dt)
+            prec = self.precision or config.precision()
+            self._store = ParamStore(list(self.named_parameters()), config.dtype_code(prec), x3=config.is_x3(prec))
             register_encoder_shadows(self._store, "", self.embed_dim, len(self.layers), biprojection=self.biprojection)
             self._store.finalize_shadows()
             self._plans = {}

@@ -191,7 +191,7 @@ def test_f9_cfg1_shape(prec, prune):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "f10_cfg3.npz")), reason="f10 fixture not generated")
 @pytest.mark.parametrize("prune", SCHEDULES)
-@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])        # (bf16x3: its split products need >= 256 rows per problem -- F9 / F11)
 def test_f10_cfg3_shape(prec, prune):
     """BASELINE.json configs[2] dims: 4-modal mmtrvapt, d=768, 6 heads (head_dim 128: the multi-tile attention forward /
     dQ / dK-dV kernels at T=512 / S=200 and 200 / 512), 5 layers, orig_d_v=4096 (K=4096 projection GEMM), biprojection
@@ -234,7 +234,7 @@ def test_f11_headline(prec, prune):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(G, "f12_k768.npz")), reason="f12 fixture not generated")
 @pytest.mark.parametrize("prune", SCHEDULES)
-@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])        # (bf16x3: its split products need >= 256 rows per problem -- F9 / F11)
 def test_f12_kernel_point_model(prec, prune):
     """The north-star kernel-point model against the reference itself (BASELINE.json north_star: hidden 768 / seq_len 50;
     bench.py `k768` and `kernel_point`): `mmtrvat` at d=768, 6 heads (head_dim 128), 5 layers, T = S = 50 in all twelve
