@@ -603,7 +603,7 @@ class EncoderGroupPlan:
     def _pn(self, e: EncoderDesc, i: int, leaf: str) -> str:
         return f"{e.prefix}layers.{i}.{leaf}"
 
-    def _gemm(self, variant, probs, background=False):
+    def _gemm(self, variant, probs, background=False, presplit=()):
         # every operand of the encoder GEMMs is a CT buffer written by this library (LayerNorm / cast / epilogue /
         # attention outputs into zero-initialised padded rows, packed weight shadows): the k padding is zero
         # background: weight gradients only.  The side stream's K/V projections and K/V dgrads measured better WITH the
@@ -612,6 +612,9 @@ class EncoderGroupPlan:
             p.flags |= F_KPAD | (F_BACKGROUND if background else 0)
         arr = ops.array(GemmProblem, probs)
         arr.x3 = self.store.x3                       # bf16x3 mode: ops.gemm_grouped splits the operands of eligible launches
+        # ... except operands whose split image an earlier launch of the same step has left: the forward activations a
+        # weight gradient reads again, and gradients the main stream's data-gradient product of this layer has just split
+        arr.x3_presplit = frozenset(t.data_ptr() for t in presplit)
         return (ops.gemm_grouped, self.dtype, variant, arr)
 
     # -- forward tables ---------------------------------------------------------
@@ -841,6 +844,7 @@ class EncoderGroupPlan:
             wg_att, dg_out, att, dg_q, lnq = [], [], [], [], []
             s_cast0, s_dgout0, s_att0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], []
             s_dgq, s_scatter = [], []                 # tail_rows (last layer): d(LN0 rows {0, T-1}) and the scatter back to [R, d]
+            pre_ffn, pre_att = [], []                 # bf16x3: operands of the weight gradients whose split image already exists
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
                 Rq, Tq = b["Rl"][i], b["Tl"][i]                        # query-side rows / time steps of this layer
@@ -867,6 +871,8 @@ class EncoderGroupPlan:
                                              drop_p=pr(c.res_dropout), drop_site=site(e.enc_id, i - 1, S_RES2))
                 if c.biprojection:
                     dy0, dqs, dks, dvs = (b[n][par] for n in ("dy0", "dqs", "dks", "dvs"))
+                pre_ffn += [dyf, dh1, b["h1"][i], b["xn2"][i]]
+                pre_att += [dy, dq, b["ao"][i], b["xq"][i] if c.biprojection else b["xn"][i], b["khat"], b["vhat"]]
                 # ---- FFN
                 wg_ffn.append(ops.gemm_problem(dyf, b["h1"][i], GP("fc2.weight"), d, 4 * d, Rq, ld, ld4, 4 * d,
                                                flags=ACC1))
@@ -961,18 +967,21 @@ class EncoderGroupPlan:
             # Side stream (SIDE): weight gradients and the key/value-side dgrad + LayerNorm backward -- nothing on
             # the backward critical path consumes them.  Temporaries are double-buffered by layer parity, so the
             # main chain only waits (WAIT) for the side work of two layers ago before overwriting them.
+            x3 = st.x3
+            wg_ffn_step = (SIDE, self._gemm(GEMM_TN, wg_ffn, background=True, presplit=pre_ffn if x3 else ()))
+            wg_att_step = (SIDE, self._gemm(GEMM_TN, wg_att, background=True, presplit=pre_att if x3 else ()))
+            # (bf16x3: the weight gradients are launched BEHIND the data-gradient products that split the same gradients --
+            # dg_fc1 splits dh1, dg_q splits dq -- so that the side stream finds those images instead of splitting again)
             steps += [(WAIT, i + 2),
-                      self._gemm(GEMM_NN, dg_fc2),
-                      (SIDE, self._gemm(GEMM_TN, wg_ffn, background=True)),
-                      self._gemm(GEMM_NN, dg_fc1),
-                      (ops.ln_bwd, A(LnProblem, lnf), d),
+                      self._gemm(GEMM_NN, dg_fc2)] + ([] if x3 else [wg_ffn_step]) + \
+                     [self._gemm(GEMM_NN, dg_fc1)] + ([wg_ffn_step] if x3 else []) + \
+                     [(ops.ln_bwd, A(LnProblem, lnf), d),
                       self._gemm(GEMM_NN, dg_out),
                       (ops.attn_bwd_dq, self.dtype, A(AttnProblem, att)),
                       # dK / dV feed only side work: beside the main chain where the side stream has slack (see _DKV_SIDE_ENV)
                       ((SIDE if self._dkv_side == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
-                       if self._dkv_side in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att))),
-                      (SIDE, self._gemm(GEMM_TN, wg_att, background=True)),
-                      self._gemm(GEMM_NN, dg_q)]
+                       if self._dkv_side in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))] + \
+                     ([] if x3 else [wg_att_step]) + [self._gemm(GEMM_NN, dg_q)] + ([wg_att_step] if x3 else [])
             if lnq:
                 steps.append((ops.ln_bwd, A(LnProblem, lnq), d))
             if c.biprojection:

@@ -378,6 +378,8 @@ class _Trunk:
     def forward(self, feats: Dict[str, torch.Tensor], seed: int, training: bool) -> List[torch.Tensor]:
         """The caller has refreshed the weight shadows (ParamStore.refresh_shadows: a host-side decision, so it stays
         outside a captured graph)."""
+        if self.st.x3:
+            ops.x3_new_step()                        # bf16x3: split images of earlier passes are stale from here on
         self.conv_forward(feats, seed, training)
         px = self.px
         q1 = [px[q] for (q, kv, _) in LEVEL1.values()]

@@ -63,6 +63,9 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, anchor, x_q, x_k, x_v, enc):
         plan = enc._plan_for(x_q, x_k)
         enc._store.refresh_shadows()
+        if enc._store.x3:
+            from .. import ops
+            ops.x3_new_step()
         out = plan.forward([x_q.detach().contiguous()], [x_k.detach().contiguous()], [x_v.detach().contiguous()],
                            enc._next_seed(), enc.training)[0]
         ctx.enc, ctx.plan = enc, plan

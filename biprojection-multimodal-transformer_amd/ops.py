@@ -120,7 +120,9 @@ def gemm_grouped(dtype: int, variant: int, probs, seed: int = 0, n: Optional[int
             arr._x3_plan = plan              # tables are replayed every step; lists were turned into a fresh array above
         if plan.ok:
             plan.run(L, variant, _seed(seed), s)
-            return
+            if plan.rest is None:
+                return
+            arr, n = plan.rest, None            # the problems the split path does not take: exact fp32 products
     for sub, k in _chunks(arr, GemmProblem, n, GEMM_MAX_GROUP):
         _lib.check(L.bpm_gemm_grouped(dtype, variant, sub, k, _seed(seed), s), "bpm_gemm_grouped")
 
@@ -165,22 +167,42 @@ def x3_refresh_static() -> None:
         _split(_lib.lib(), list(_X3_STATIC_SPLITS.values()), _stream())
 
 
+_X3_EPOCH = [0]                 # bumped once per forward pass (x3_new_step)
+_X3_FRESH = {}                  # operand key -> epoch of its last split (host program order)
+
+
+def x3_new_step() -> None:
+    _X3_EPOCH[0] += 1
+
+
 class _X3Plan:
-    """Split problems + the BPM_BF16X3 problem table of one grouped GEMM launch (built once per launch table)."""
+    """Split problems + the BPM_BF16X3 problem table of one grouped GEMM launch (built once per launch table).
+    Problems the split path does not take (fewer than 256 rows / columns / k, row bias, ...) stay behind in `rest` and run
+    as exact fp32 products.  Operands listed in the table's `x3_presplit` attribute (set where the launch tables are
+    built: forward activations a backward launch reads again, gradients an earlier launch of the same layer has split)
+    are not split again when their image is from this step."""
 
     def __init__(self, arr, variant: int, n: Optional[int]):
         self.n = n
         cnt = len(arr) if n is None else n
         P = [arr[i] for i in range(cnt)]
         xk, yk = variant != GEMM_TN, variant == GEMM_NT
-        self.ok = all(self._eligible(p) for p in P) and cnt <= GEMM_MAX_GROUP
-        if self.ok and variant == GEMM_TN:            # one 256 x 256 tile per CU must roughly fill the chip (as in bf16 mode)
-            self.ok = sum(((p.M + 255) // 256) * ((p.N + 255) // 256) for p in P) * 8 >= 256 * 3
+        take = [p for p in P if self._eligible(p)]
+        if take and variant == GEMM_TN:               # one 256 x 256 tile per CU must roughly fill the chip (as in bf16 mode)
+            if sum(((p.M + 255) // 256) * ((p.N + 255) // 256) for p in take) * 8 < 256 * 3:
+                take = []
+        self.ok = bool(take)
+        self.rest = None
+        self._keys = []
         if not self.ok:
             return
+        if len(take) < cnt:
+            ids = {C.addressof(p) for p in take}
+            self.rest = array(GemmProblem, [p for p in P if C.addressof(p) not in ids])
+        presplit = getattr(arr, "x3_presplit", ())
         dyn, new_static, out = [], [], []
         seen = {}
-        for p in P:
+        for p in take:
             q = GemmProblem()
             C.memmove(C.byref(q), C.byref(p), C.sizeof(GemmProblem))
             for side, rows, cols, ld in (("A", p.M if xk else p.K, p.K if xk else p.M, p.lda),
@@ -202,8 +224,11 @@ class _X3Plan:
                         if key not in _X3_STATIC_SPLITS:
                             _X3_STATIC_SPLITS[key] = sp
                             new_static.append(sp)
+                    elif ptr in presplit and _X3_FRESH.get(key) == _X3_EPOCH[0]:
+                        pass                          # an earlier launch of this step left the image (static launch order)
                     else:
                         dyn.append(sp)
+                        self._keys.append(key)
                 setattr(q, side, buf.data_ptr())
                 setattr(q, "lda" if side == "A" else "ldb", 2 * ldp)
             q.flags |= F_KPAD
@@ -226,6 +251,8 @@ class _X3Plan:
         if self.dyn is not None:
             for sub, k in _chunks(self.dyn, _lib.SplitProblem, None):
                 _lib.check(L.bpm_split_rows(sub, k, s), "bpm_split_rows")
+            for key in self._keys:
+                _X3_FRESH[key] = _X3_EPOCH[0]
         _lib.check(L.bpm_gemm_grouped(_lib.BPM_BF16X3, variant, self.gemm, len(self.gemm), seed, s), "bpm_gemm_grouped(bf16x3)")
 
 
