@@ -708,6 +708,119 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// skinny kernel: problems of at most 16 rows (the query side of the level-2 encoders under dead-row elimination: rows
+// {0, N-1} x batch -- SURVEY A.10).  Such a product is a weight-streaming operation (1.2 MB of weights against 25 KB of
+// activations at hidden 768) and the 128 x 64 kernel spent it on latency: one workgroup per 64 columns walking all of K
+// through LDS stages with a barrier each (28-37 us per launch for ~3 us of memory traffic; 95-105 us with fp32 operands).
+// Here a workgroup still owns 16 rows x 64 columns, but its four waves split K between them, every wave loads its MFMA
+// operands straight from global memory (k-contiguous X and, for NT, W rows: 16 bytes per lane, all loads of a chunk of
+// k-steps in flight before the first MFMA; for NN the [k][n] weight slice goes through a wave-private LDS block and is
+// read back transposed), and the four partial tiles are summed through LDS before the shared epilogue.
+// ---------------------------------------------------------------------------
+constexpr int SK_CHUNK = 6;            // k-steps (64 bytes of k each) whose loads are in flight together per wave
+
+template <typename CT, bool YK>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const Group grp) {
+    typedef typename Tr<CT>::frag frag;
+    constexpr int SZ = sizeof(CT), KS = Tr<CT>::KSTEP, EPC = Tr<CT>::EPC;
+    constexpr int YSTRIDE = 64 * SZ + Tr<CT>::TR_PAD_B;          // wave-private [k][64 n] image of one k-step (NN)
+    constexpr int YIMG = KS * YSTRIDE;
+    __shared__ __attribute__((aligned(16))) char smem[4 * 4 * 64 * 16 > 4 * YIMG ? 4 * 4 * 64 * 16 : 4 * YIMG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const Prob& P = pick_problem(grp, bid);
+    if (BPM_BASE_PRIO && !(P.flags & BPM_GEMM_BACKGROUND)) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
+    const int n0 = bid * 64;
+    const int nks = (P.K + KS - 1) / KS;
+    const int per = (nks + 3) >> 2;
+    const int ks_lo = wave * per, ks_hi = min(nks, ks_lo + per);
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool xrow_ok = r < P.M;
+    const char* xrow = P.X + (size_t)(xrow_ok ? r : 0) * P.ldx * SZ + g * 16;          // + ks * 64: this lane's chunk of k-step ks
+    char* yimg = smem + wave * YIMG;
+
+#pragma unroll 1
+    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += SK_CHUNK) {
+        frag fx[SK_CHUNK];
+#pragma unroll
+        for (int c = 0; c < SK_CHUNK; ++c) {
+            const int ks = min(ks0 + c, ks_hi - 1);              // clamped: always a valid address; surplus steps are skipped below
+            fx[c] = *(const frag*)(xrow + (size_t)ks * 64);
+            if (!xrow_ok) fx[c] = Tr<CT>::zero();
+        }
+        if constexpr (YK) {
+            frag fy[SK_CHUNK][4];
+#pragma unroll
+            for (int c = 0; c < SK_CHUNK; ++c) {
+                const int ks = min(ks0 + c, ks_hi - 1);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int n = n0 + 16 * a + r;
+                    fy[c][a] = *(const frag*)(P.Y + (size_t)(n < P.N ? n : 0) * P.ldy * SZ + (size_t)ks * 64 + g * 16);
+                    if (n >= P.N) fy[c][a] = Tr<CT>::zero();
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < SK_CHUNK; ++c)
+                if (ks0 + c < ks_hi) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] = Tr<CT>::mma(fy[c][a], fx[c], acc[a]);
+                }
+        } else {
+            // W[k][n] rows of this k-step: KS rows x 64 columns = 4 chunks of 16 bytes per lane
+            constexpr int CPR = 64 * SZ / 16;                    // 16-byte chunks per k-row
+            constexpr int PT = KS * CPR / 64;                    // chunks per lane and k-step
+            u32x4 yv[SK_CHUNK][PT];
+#pragma unroll
+            for (int c = 0; c < SK_CHUNK; ++c) {
+                const int ks = min(ks0 + c, ks_hi - 1);
+#pragma unroll
+                for (int i = 0; i < PT; ++i) {
+                    const int ch = lane + 64 * i, kr = ch / CPR, cc = ch % CPR;
+                    const int k = ks * KS + kr, n = n0 + cc * EPC;
+                    const bool ok = k < P.K && n + EPC <= P.ldy && n < P.N;
+                    yv[c][i] = *(const u32x4*)(P.Y + ((size_t)(ok ? k : 0) * P.ldy + (ok ? n : 0)) * SZ);
+                    if (!ok) yv[c][i] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < SK_CHUNK; ++c)
+                if (ks0 + c < ks_hi) {                            // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) {
+                        const int ch = lane + 64 * i, kr = ch / CPR, cc = ch % CPR;
+                        *(u32x4*)(yimg + kr * YSTRIDE + cc * 16) = yv[c][i];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // one wave: its LDS accesses execute in order
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[a] = Tr<CT>::mma(Tr<CT>::read_tr(yimg, YSTRIDE, 0, 16 * a, lane, Tr<CT>::TR_NATURAL), fx[c], acc[a]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next k-step overwrites the image
+                }
+        }
+    }
+    // the four waves' partial tiles -> LDS; wave w sums and finishes column tile w
+    __syncthreads();
+    f32x4* red = (f32x4*)smem;                                   // [wave][a][lane]
+#pragma unroll
+    for (int a = 0; a < 4; ++a) red[(wave * 4 + a) * 64 + lane] = acc[a];
+    __syncthreads();
+    f32x4 t = red[(0 * 4 + wave) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += red[(w * 4 + wave) * 64 + lane];
+    const bool fast = epi_fast_ok(P);
+    const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
+    f32x4 tile[1] = {t};
+    EpiRow rows[1] = {epi_row(P, r)};
+    epilogue_cols<CT, 1>(P, drop, fast, true, 0, r, n0 + 16 * wave + 4 * g, tile, rows);
+}
+
 #include "gemm_dma.h"
 
 template <typename CT>
@@ -906,9 +1019,17 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
             }
         }
     }
+    // at most 16 rows per problem (level-2 query side under dead-row elimination): the skinny kernel (see there)
+    bool skinny = dma < 0 && !x3 && variant != BPM_GEMM_TN && fast;
+    for (int i = 0; i < nprob && skinny; ++i) {
+        const bpm_gemm_problem& q = probs[i];
+        skinny = q.M <= 16 && q.splitk <= 1 && !(q.flags & (BPM_GEMM_ATOMIC | BPM_GEMM_A_OVERLAP | BPM_GEMM_B_OVERLAP)) &&
+                 ((long)q.lda * sz) % 64 == 0 && (variant != BPM_GEMM_NT || ((long)q.ldb * sz) % 64 == 0);
+    }
     // under-filled weight-gradient launches (fewer than two 128-row workgroups per CU) run 64-row workgroups:
     // measured 98 -> 77 us for the 24 attention weight gradients of a layer (360 -> 600 workgroups)
     int bm_tile = BM, bn_tile = BN;
+    if (skinny) { bm_tile = 16; bn_tile = 64; }
     if (dma >= 0) { bm_tile = DMA_CFGS[dma].bm; bn_tile = DMA_CFGS[dma].bn; }
     else if (variant == BPM_GEMM_TN && fast && BM == 128) {
         long t128 = 0;
@@ -966,6 +1087,18 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     BpmProfScope prof((dma >= 0 ? BPM_K_GEMM_DMA_NT : BPM_K_GEMM_NT) + variant, s, flops, bytes);
     if (x3 && dma < 0) return BPM_ERR_ARG;
     if (dma >= 0) return launch_dma(dma, variant, g, s, x3);
+    if (skinny) {
+        dim3 grid(g.total_tiles), block(256);
+        if (dtype == BPM_BF16) {
+            if (variant == BPM_GEMM_NT) hipLaunchKernelGGL((gemm_skinny_kernel<bf16_t, true>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<bf16_t, false>), grid, block, 0, s, g);
+        } else {
+            if (variant == BPM_GEMM_NT) hipLaunchKernelGGL((gemm_skinny_kernel<float, true>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<float, false>), grid, block, 0, s, g);
+        }
+        BPM_CHECK_LAUNCH();
+        return 0;
+    }
     return dtype == BPM_BF16 ? launch<bf16_t>(variant, fast, bm_tile == 64, g, s)
                              : launch<float>(variant, fast, bm_tile == 64, g, s);
 }

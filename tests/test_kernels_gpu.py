@@ -1054,3 +1054,57 @@ def test_gemm_bf16x3_at_the_model_launch_shapes(variant):
         close(outs[gi], refs[gi], 5e-5, f"problem {gi}")
         if sums[gi][0] is not None:
             close(sums[gi][0], sums[gi][1], 5e-5, f"column sums of X, problem {gi}")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("variant,M,N,K", [(GEMM_NT, 16, 768, 768), (GEMM_NT, 2, 3072, 768), (GEMM_NT, 9, 300, 300),
+                                          (GEMM_NN, 16, 768, 3072), (GEMM_NN, 4, 3072, 768), (GEMM_NN, 16, 300, 1200)])
+def test_gemm_skinny_rows(dtype, variant, M, N, K):
+    """Problems of at most 16 rows (the level-2 query side under dead-row elimination: rows {0, N-1} x batch) take the
+    skinny kernel -- K split over the four waves of a workgroup, operands straight from global memory, partial tiles
+    summed through LDS -- with the shared epilogue: every fused epilogue the encoder uses on such launches, against fp64
+    on the CT-rounded operands; dropout masks equal to the other kernels' (host restatement of the hash)."""
+    from bpmult_amd.ops import F_KPAD
+    dev = DEV
+    A, Ar = to_ct(rnd(M, K, seed=51), dtype)
+    if variant == GEMM_NT:
+        Bm, Br = to_ct(rnd(N, K, seed=52, scale=K ** -0.5), dtype)
+        ref = Ar.double() @ Br.double().T
+    else:
+        Bm, Br = to_ct(rnd(K, N, seed=52, scale=K ** -0.5), dtype)
+        ref = Ar.double() @ Br.double()
+    t = tol(dtype) if dtype == BPM_F32 else 4e-3
+    bias, resid = rnd(N, seed=53).to(dev), rnd(M, N, seed=54).to(dev)
+    gate, gr = to_ct(rnd(M, N, seed=55), dtype)
+    base = rnd(M, N, seed=56).to(dev)
+    o1 = torch.full((M, N), float("nan"), device=dev)
+    o2 = torch.full((M, pad32(N)), float("nan"), device=dev).to(ops.ct_torch(dtype))
+    o3 = torch.full((M, pad32(N)), float("nan"), device=dev).to(ops.ct_torch(dtype))
+    o5 = base.clone()
+    cs = torch.zeros(N, device=dev)
+    ps = [ops.gemm_problem(A, Bm, o1, M, N, K, A.shape[1], Bm.shape[1], N, bias_n=bias, resid=resid, ldr=N, drop_p=0.25, drop_site=9, flags=F_KPAD),
+          ops.gemm_problem(A, Bm, o2, M, N, K, A.shape[1], Bm.shape[1], pad32(N), bias_n=bias, flags=F_KPAD | F_RELU, drop_p=0.1, drop_site=3, out_kind=OUT_CT),
+          ops.gemm_problem(A, Bm, o3, M, N, K, A.shape[1], Bm.shape[1], pad32(N), gate=gate, ldg=gate.shape[1], gate_scale=1.25, colsum=cs, flags=F_KPAD, out_kind=OUT_CT),
+          ops.gemm_problem(A, Bm, o5, M, N, K, A.shape[1], Bm.shape[1], N, flags=F_KPAD | F_ACCUM)]
+    heads = None
+    if N % 12 == 0 and M % 2 == 0:                       # head-major scatter: rows are (t, b) with B = M / 2
+        Hn, dh = 12, N // 12
+        dhp = 32 if dh <= 32 else 64 if dh <= 64 else 128 if dh <= 128 else 256
+        if dhp <= 128:
+            heads = torch.zeros(M // 2, Hn, 2, dhp, device=dev, dtype=ops.ct_torch(dtype))
+            ps.append(ops.gemm_problem(A, Bm, heads, M, N, K, A.shape[1], Bm.shape[1], 0, bias_n=bias, alpha=0.5, out_kind=OUT_HEADS,
+                                       heads=(M // 2, Hn, 2, dh, dhp), flags=F_KPAD))
+    ops.gemm_grouped(dtype, variant, ps, seed=77)
+    torch.cuda.synchronize()
+    rb = ref + bias.cpu().double()
+    close(o1, rb * drop_mult((M, N), 0.25, 77, 9).double() + resid.cpu().double(), 2 * t, "bias + dropout + residual")
+    close(o2[:, :N], rb.clamp_min(0) * drop_mult((M, N), 0.1, 77, 3).double(), 2 * t, "relu + dropout -> CT")
+    if pad32(N) > N:
+        assert float(o2[:, N:].float().abs().max()) == 0.0 and float(o3[:, N:].float().abs().max()) == 0.0
+    g3 = torch.where(gr.double() > 0, ref * 1.25, torch.zeros_like(ref))
+    close(o3[:, :N], g3, 2 * t, "gate -> CT")
+    close(cs, g3.sum(0), 4 * t, "column sums")
+    close(o5, ref + base.cpu().double(), t, "+=")
+    if heads is not None:
+        want = ((rb * 0.5).reshape(2, M // 2, 12, N // 12)).permute(1, 2, 0, 3)      # [B, H, T, dh]
+        close(heads[..., :N // 12], want, 2 * t, "head-major")
