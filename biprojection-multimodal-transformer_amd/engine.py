@@ -589,6 +589,10 @@ class EncoderGroupPlan:
                 ud.append(u)
             self._unfold.append((ops.device_table(ud), len(ud), blk))
         self._dkv_side = _DKV_SIDE_ENV if _DKV_SIDE_ENV != "auto" else ("1" if d >= 512 else "0")
+        # a group whose query side is a handful of rows (level 2 under dead-row elimination) is bound by its SIDE stream
+        # (key / value projections, their weight gradients): its dK / dV pass goes back to the main stream, which idles
+        if _DKV_SIDE_ENV == "auto" and max(e.T for e in self.encs) * B <= 64:
+            self._dkv_side = "0"
         self._side_low = d < 512
         self.store.side_low = self._side_low
         self._fwd = {True: self._build_fwd(True), False: self._build_fwd(False)}
