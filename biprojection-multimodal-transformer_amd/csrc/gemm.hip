@@ -856,18 +856,18 @@ int launch(int variant, bool fast, bool bm64, const Group& g, hipStream_t s) {
 }
 
 // LDS-DMA kernel configurations: (waves along m, waves along n, m tiles per wave, stages); X3: split-bf16 operands
-template <int WMD, int WND, int TMW, int NS, bool X3 = false>
+template <int WMD, int WND, int TMW, int NS, bool X3 = false, int DKT = DK>
 int launch_dma_cfg(int variant, const Group& g, hipStream_t s) {
     dim3 grid(g.total_tiles), block(64 * WMD * WND);
     switch (variant) {
-        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_dma_kernel<true, true, WMD, WND, TMW, NS, false, X3>), grid, block, 0, s, g); break;
-        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_dma_kernel<true, false, WMD, WND, TMW, NS, false, X3>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NT: hipLaunchKernelGGL((gemm_dma_kernel<true, true, WMD, WND, TMW, NS, false, X3, DKT>), grid, block, 0, s, g); break;
+        case BPM_GEMM_NN: hipLaunchKernelGGL((gemm_dma_kernel<true, false, WMD, WND, TMW, NS, false, X3, DKT>), grid, block, 0, s, g); break;
         case BPM_GEMM_TN:
             if constexpr ((16 * TMW * WMD) % 128 == 0) {
                 bool xs = false;
                 for (int i = 0; i < g.nprob; ++i) xs = xs || g.p[i].colsum_x != nullptr;
-                if (xs) hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, true, X3>), grid, block, 0, s, g);
-                else hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, false, X3>), grid, block, 0, s, g);
+                if (xs) hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, true, X3, DKT>), grid, block, 0, s, g);
+                else hipLaunchKernelGGL((gemm_dma_kernel<false, false, WMD, WND, TMW, NS, false, X3, DKT>), grid, block, 0, s, g);
             } else return BPM_ERR_ARG;         // k-strided X: 128-column sub-images only
             break;
         default: return BPM_ERR_ARG;
@@ -877,8 +877,9 @@ int launch_dma_cfg(int variant, const Group& g, hipStream_t s) {
 }
 
 struct DmaCfg { int bm, bn; };
-constexpr DmaCfg DMA_CFGS[] = {{128, 128}, {256, 128}, {256, 256}, {256, 256}, {128, 128}, {320, 256}};
+constexpr DmaCfg DMA_CFGS[] = {{128, 128}, {256, 128}, {256, 256}, {256, 256}, {128, 128}, {320, 256}, {256, 128}};
 constexpr int CFG_TALL = 5;               // 320-row tiles (k-contiguous X only): see the tile choice in bpm_gemm_grouped
+constexpr int CFG_TWO = 6;                // 256 x 128, 32-k stages, three of them: two workgroups per CU (gemm_dma.h)
 constexpr int N_DMA_CFGS = sizeof(DMA_CFGS) / sizeof(DMA_CFGS[0]);
 
 int launch_dma(int cfg, int variant, const Group& g, hipStream_t s, bool x3 = false) {
@@ -897,6 +898,7 @@ int launch_dma(int cfg, int variant, const Group& g, hipStream_t s, bool x3 = fa
         case 3: return launch_dma_cfg<4, 4, 4, 2>(variant, g, s);      // 256 x 256, 16 waves of 64 x 64
         case 4: return launch_dma_cfg<2, 2, 4, 3>(variant, g, s);      // 128 x 128,  3 stages
         case CFG_TALL: return launch_dma_cfg<2, 4, 10, 2>(variant, g, s);   // 320 x 256, 8 waves of 160 x 64 (NT / NN)
+        case CFG_TWO: return launch_dma_cfg<4, 2, 4, 3, false, 32>(variant, g, s);   // 256 x 128, 8 waves of 64 x 64, 3 stages of 32 k: 72 KB
     }
     return BPM_ERR_ARG;
 }
@@ -1001,6 +1003,32 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         if (legal && g_force_dma >= 0 && !x3) dma = g_force_dma == CFG_TALL && variant == BPM_GEMM_TN ? -1 : g_force_dma;
         else if (legal && big) {
             dma = variant == BPM_GEMM_TN ? 2 : 3;
+            // Two resident workgroups per CU (256 x 128 tiles, 32-k stages; gemm_dma.h) where they measured faster than the
+            // one-per-CU tiles (tools/gemm_lab.py, hidden 768, six problems of 4096 rows): the FFN weight gradients
+            // 328 -> 279 us (their k loop is LDS-fill bound: a second workgroup's loads and a third stage fill the gaps);
+            // twelve-problem K / V projections 104 -> 94.  Not for weight gradients that carry the bias column sums (the
+            // extra accumulators spill at 128 registers: 156 -> 253 us) nor for the N = 768 products, where 320 x 256 tiles
+            // fit one round (q 55 -> 59, fc2 124 -> 178).  Inside the step (bench.py, hidden 768, ms per step; BPMULT_TWO_MASK
+            // is the lab switch for these classes): none 19.97-20.03, weight gradients + K / V 19.65-19.82, + fc1 (N >= 2048
+            // forward products) 19.44, + d(fc2) 19.54-19.80, every N = 768 product 20.22.
+            bool xs_any = false;
+            long kmin = 1l << 30, kmax = 0, nmax = 0, mmax = 0;
+            for (int i = 0; i < nprob; ++i) {
+                xs_any = xs_any || probs[i].colsum_a != nullptr;
+                kmin = probs[i].K < kmin ? probs[i].K : kmin;
+                kmax = probs[i].K > kmax ? probs[i].K : kmax;
+                nmax = probs[i].N > nmax ? probs[i].N : nmax;
+                mmax = probs[i].M > mmax ? probs[i].M : mmax;
+            }
+            static const int two_mask = std::getenv("BPMULT_TWO_MASK") ? std::atoi(std::getenv("BPMULT_TWO_MASK")) : 7;
+            // (hidden 1536, `bench.py --config cfg5`: the weight-gradient and fc1 classes each cost 1 % there -- 70.7 -> 71.4 / 71.6
+            // ms -- so they are tied to hidden <= 1024: weight gradients of at most 1024 rows, forward products of K <= 1024)
+            const bool two_tn = (two_mask & 1) && variant == BPM_GEMM_TN && !xs_any && kmin >= 1024 && mmax <= 1024 && !x3;
+            bool two_kv = (two_mask & 2) && variant == BPM_GEMM_NT && nprob >= 12 && nmax <= 1024 && !x3;
+            if ((two_mask & 4) && variant == BPM_GEMM_NT && nmax >= 2048 && kmax <= 1024 && !x3) two_kv = true;          // fc1
+            if ((two_mask & 8) && variant == BPM_GEMM_NN && nmax >= 2048 && !x3) two_kv = true;          // d(fc2)
+            if ((two_mask & 16) && variant == BPM_GEMM_TN && xs_any && !x3) two_kv = true;               // attention weight gradients
+            if ((two_mask & 32) && variant != BPM_GEMM_TN && nmax <= 1024 && !x3) two_kv = true;         // every N = 768 product
             if (variant != BPM_GEMM_TN) {
                 // One workgroup per CU: a launch takes ceil(tiles / CUs) rounds of one tile each, and at the model's
                 // shapes the tile count sits just above a multiple of the CU count (six problems of 4096 x 768 are 288
@@ -1017,6 +1045,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
                 const long r256 = (t256 + ncu - 1) / ncu, r320 = (t320 + ncu - 1) / ncu;
                 if (r320 * 320 * 21 < r256 * 256 * 20) dma = CFG_TALL;
             }
+            if (two_tn || two_kv) dma = CFG_TWO;
         }
     }
     // at most 16 rows per problem (level-2 query side under dead-row elimination): the skinny kernel (see there)

@@ -167,21 +167,33 @@ BPM_DEV void wide_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, co
     }
 }
 
-// One operand side of the workgroup tile: ROWS rows of the output (a multiple of 128), NW waves in the workgroup.
-template <bool KCONTIG, int ROWS, int NW>
+// One operand side of the workgroup tile: ROWS rows of the output (a multiple of 128), NW waves in the workgroup, DKT
+// k elements per stage: 64 (128-byte rows: whole lines) or 32 (64-byte rows: the two-resident-workgroup configuration,
+// whose three stages of a 256 x 128 tile are 72 KB).
+template <bool KCONTIG, int ROWS, int NW, int DKT = DK>
 struct DmaSide {
-    static constexpr int IMG_BYTES = ROWS * DROW;                 // both layouts: ROWS * 64 k * 2 B
+    static constexpr int ROWB = DKT * 2;                          // bytes of k per row-image row
+    static constexpr int IMG_BYTES = ROWS * ROWB;                 // both layouts: ROWS * DKT k * 2 B
     static constexpr int PIECES = IMG_BYTES / 1024;
     static constexpr int PER_WAVE = PIECES / NW;
+    static constexpr int RPP = 1024 / ROWB, SPR = ROWB / 16;      // row image: rows per 1 KB piece, 16-byte slots per row
+    static constexpr int PPS = DKT / 4, SUB_BYTES = DKT * 256;    // col image: pieces per 128-column sub-image, its bytes
+    static_assert(DKT == 64 || DKT == 32, "64 or 32 k per stage");
     static_assert(PIECES % NW == 0 && (KCONTIG || ROWS % 128 == 0), "pieces divide over the waves; k-strided images are 128-column sub-images");
     static_assert(NW == 4 || NW == 8 || NW == 16, "piece -> swizzle mapping assumes 4, 8 or 16 waves");
+    static_assert(KCONTIG || NW <= PPS, "a wave's first piece lies in the first sub-image");
+
+    // 16-byte chunk c of row r of a row image sits at chunk c ^ swz(r): conflict free for ds_read_b128's lane groups
+    // (128-byte rows: see the header comment; 64-byte rows: the 128 x 64 kernel's swz4)
+    static BPM_DEV int row_swz(int row) { return DKT == 64 ? ((row >> 1) & 7) : swz4(row); }
+    static BPM_DEV int row_off(int row, int c) { return row * ROWB + ((c ^ row_swz(row)) << 4); }
 
     // Wave w moves pieces w, w + NW, ...  The per-lane byte offset of its piece 0 -- the other pieces differ by a
-    // wave-uniform amount because the swizzle term repeats every 2 (row image) / 4 (col image) pieces.
+    // wave-uniform amount because the swizzle term repeats every 16 rows (row image) / 16 k-rows (col image).
     static BPM_DEV int voffset(int ld, int row0, int wave, int lane) {
         if (KCONTIG) {
-            const int row = 8 * wave + (lane >> 3), slot = lane & 7;
-            return (row0 + row) * ld * 2 + ((slot ^ ((row >> 1) & 7)) << 4);
+            const int row = RPP * wave + lane / SPR, slot = lane % SPR;
+            return (row0 + row) * ld * 2 + ((slot ^ row_swz(row)) << 4);
         }
         const int kr = 4 * wave + (lane >> 4), slot = lane & 15;      // piece = 4 k-rows of one 128-column sub-image
         const int x = ((kr & 3) << 2) | ((kr >> 2) & 3);
@@ -189,14 +201,14 @@ struct DmaSide {
     }
     // wave-uniform byte offset of piece j relative to piece 0, and its LDS offset inside the image
     static BPM_DEV int piece_goff(int ld, int j) {
-        if (KCONTIG) return j * 8 * NW * ld * 2;
-        return ((NW * j) >> 4) * 256 + 4 * ((NW * j) & 15) * ld * 2;     // sub-image (128 columns), then k-rows
+        if (KCONTIG) return j * RPP * NW * ld * 2;
+        return ((NW * j) / PPS) * 256 + 4 * ((NW * j) % PPS) * ld * 2;     // sub-image (128 columns), then k-rows
     }
     static BPM_DEV int piece_lds(int wave, int j) {
         if (KCONTIG) return (wave + j * NW) * 1024;
-        return ((NW * j) >> 4) * 16384 + (wave + ((NW * j) & 15)) * 1024;
+        return ((NW * j) / PPS) * SUB_BYTES + (wave + ((NW * j) % PPS)) * 1024;
     }
-    static BPM_DEV int stage_step(int ld) { return KCONTIG ? DROW : DK * ld * 2; }
+    static BPM_DEV int stage_step(int ld) { return KCONTIG ? ROWB : DKT * ld * 2; }
 
     // DMA instruction j of this wave for one stage (soff: byte offset of the stage's k position).  A __device__
     // function: with the LDS-DMA builtin directly in the kernel's lambda the host pass silently drops the kernel stub.
@@ -209,9 +221,9 @@ struct DmaSide {
     // MFMA operand of the 16 rows starting at r0 (multiple of 16), k-step ks (0 / 1) of the stage
     static BPM_DEV bf16x8 frag(const char* img, int r0, int ks, int lane) {
         const int r = lane & 15, g = lane >> 4;
-        if (KCONTIG) return *(const bf16x8*)(img + dma_row_off(r0 + r, 4 * ks + g));
+        if (KCONTIG) return *(const bf16x8*)(img + row_off(r0 + r, 4 * ks + g));
         const int q = r >> 2, p = r & 3;
-        const char* sub = img + (r0 >> 7) * 16384;
+        const char* sub = img + (r0 >> 7) * SUB_BYTES;
         const int ch = ((r0 & 127) >> 3) + (p >> 1);
         const int k0 = 32 * ks + 8 * g + q;
         typedef bf16x4 __attribute__((address_space(3))) * lds4;
@@ -247,16 +259,22 @@ BPM_DEV void dma_issue_part(__amdgpu_buffer_rsrc_t rsx, __amdgpu_buffer_rsrc_t r
 // dimension spans both planes, so a plane is ld / 2 elements = ld BYTES further) and the product is
 // x y ~ hi hi + hi lo + lo hi: the k loop runs three segments of ceil(K / 64) stages over plane pairs (hi, hi), (hi, lo),
 // (lo, hi) into the same accumulators; CT outputs and the gate operand are fp32.  Everything else is the same kernel.
-template <bool XK, bool YK, int WMD, int WND, int TMW, int NS, bool XS = false, bool X3 = false>
-__global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group grp) {
+// DKT = 32 (256 x 128 tiles, 8 waves, three 24 KB stages, <= 128 registers per wave): TWO workgroups fit a CU, so one's
+// pipeline fill and epilogue -- memory phases during which its matrix pipes idle, 58 % of a K = 768 tile's life (DESIGN.md
+// section 5) -- overlap the other's k loop, and a workgroup waiting at its stage barrier leaves the SIMDs to the other.
+template <bool XK, bool YK, int WMD, int WND, int TMW, int NS, bool XS = false, bool X3 = false, int DKT = DK>
+__global__ __launch_bounds__(64 * WMD * WND) __attribute__((amdgpu_waves_per_eu(DKT == 32 ? 4 : (WMD * WND + 3) / 4)))
+void gemm_dma_kernel(const Group grp) {
     typedef typename std::conditional<X3, float, bf16_t>::type OT;
     static_assert(!XS || (!XK && !YK), "column sums of X belong to the weight-gradient product");
     constexpr int NW = WMD * WND, BMD = 16 * TMW * WMD, BND = 64 * WND, WROWS = 16 * TMW;
-    typedef DmaSide<XK, BMD, NW> SX;
-    typedef DmaSide<YK, BND, NW> SY;
+    typedef DmaSide<XK, BMD, NW, DKT> SX;
+    typedef DmaSide<YK, BND, NW, DKT> SY;
+    constexpr int KSPS = DKT / 32;                            // MFMA k-steps per stage
     constexpr int STAGE = SX::IMG_BYTES + SY::IMG_BYTES;
     constexpr int LPS = SX::PER_WAVE + SY::PER_WAVE;          // DMA instructions per wave and stage
     static_assert(NS == 2 || NS == 3, "2 or 3 stages");
+    static_assert(DKT == 64 || !X3, "the split-operand products use 64-k stages");
     static_assert(TMW == 4 || TMW == 8 || TMW == 10, "wave tile 64 x 64, 128 x 64 or 160 x 64");
     __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
 
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     const Prob& P = pick_problem(grp, bid);
     if (BPM_BASE_PRIO && XK && !(P.flags & BPM_GEMM_BACKGROUND)) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);
     const int m0 = (bid / P.tiles_n) * BMD, n0 = (bid % P.tiles_n) * BND;
-    const int nk1 = (P.K + DK - 1) / DK;                  // stages per plane pair
+    const int nk1 = (P.K + DKT - 1) / DKT;                // stages per plane pair
     const int nkt = X3 ? 3 * nk1 : nk1;
 
     // descriptor = exactly the bytes the operand owns: (rows - 1) leading dimensions plus the last row's width (whole k
@@ -277,8 +295,8 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     // buffer then never reads past the parent's last row (rows * ld from the view's first element would)
     // (X3: a split image is a whole allocation of rows x ld elements with zero pad columns in both planes: the range check
     // only has to cut off rows past M / N and k-rows past K)
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, X3 ? (XK ? P.M : P.K) * P.ldx * 2 : desc_bytes(XK ? P.M : P.K, P.ldx, XK ? nkt * DK : (P.M + 7) & ~7, 2, (P.flags & BPM_GEMM_A_OVERLAP) != 0), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, X3 ? (YK ? P.N : P.K) * P.ldy * 2 : desc_bytes(YK ? P.N : P.K, P.ldy, YK ? nkt * DK : (P.N + 7) & ~7, 2, (P.flags & BPM_GEMM_B_OVERLAP) != 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)P.X, 0, X3 ? (XK ? P.M : P.K) * P.ldx * 2 : desc_bytes(XK ? P.M : P.K, P.ldx, XK ? nkt * DKT : (P.M + 7) & ~7, 2, (P.flags & BPM_GEMM_A_OVERLAP) != 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)P.Y, 0, X3 ? (YK ? P.N : P.K) * P.ldy * 2 : desc_bytes(YK ? P.N : P.K, P.ldy, YK ? nkt * DKT : (P.N + 7) & ~7, 2, (P.flags & BPM_GEMM_B_OVERLAP) != 0), 0x00020000);
     const int vx = SX::voffset(P.ldx, m0, wave, lane), vy = SY::voffset(P.ldy, n0, wave, lane);
     const int stepx = SX::stage_step(P.ldx), stepy = SY::stage_step(P.ldy);
     const int ldx = P.ldx, ldy = P.ldy;
@@ -353,13 +371,17 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
             if (more && !(BPM_DMA_ABLATE & 2)) {
                 if constexpr (EARLY) {
                     if (ks == 0) stage(kt + NS - 1, nbuf);
-                } else part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks>{});
+                } else if constexpr (KSPS == 2) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks>{});
+                else { part(kt + NS - 1, nbuf, std::integral_constant<int, 0>{}); part(kt + NS - 1, nbuf, std::integral_constant<int, 1>{}); }
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < TMW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
-            if (more && !(BPM_DMA_ABLATE & 2) && !EARLY) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks + 1>{});
+            if (more && !(BPM_DMA_ABLATE & 2) && !EARLY) {
+                if constexpr (KSPS == 2) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks + 1>{});
+                else { part(kt + NS - 1, nbuf, std::integral_constant<int, 2>{}); part(kt + NS - 1, nbuf, std::integral_constant<int, 3>{}); }
+            }
 #pragma unroll
             for (int a = 2; a < 4; ++a)
 #pragma unroll
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
         };
         if (!(BPM_DMA_ABLATE & 1)) {
             step(std::integral_constant<int, 0>{});
-            step(std::integral_constant<int, 1>{});
+            if constexpr (KSPS == 2) step(std::integral_constant<int, 1>{});
         } else if (more) stage(kt + NS - 1, nbuf);
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(64 * WMD * WND) void gemm_dma_kernel(const Group gr
     const DropCfg drop = bpm_resolve_drop(P.drop, grp.seedp);
     // side operands of 16-row step h live in sd[h % (AH + 1)], requested AH steps before their use -- where the register
     // budget allows: the 16-wave configuration (128 registers) spills with two sets and requests them right before their use
-    constexpr int AH = NW < 16 ? BPM_EPI_AHEAD : 0;
+    constexpr int AH = (NW < 16 && DKT == 64) ? BPM_EPI_AHEAD : 0;
     WideSide<4, OT> sd[AH + 1];
 #pragma unroll
     for (int h0 = 0; h0 < AH; ++h0)

@@ -173,7 +173,7 @@ def test_gemm_large_tile_epilogues_match_small_tile():
     base = rnd(M, N, seed=15).to(DEV)
     res = {}
     with lab_library() as L:
-        for cfg in (-2, 3, 2, 0, 5):
+        for cfg in (-2, 3, 2, 0, 5, 6):
             _lib.check(L.bpm_debug_gemm_force(cfg), "force")
             o1 = torch.full((M, N), float("nan"), device=DEV).to(ctt)
             o2 = torch.full((M, N), float("nan"), device=DEV).to(ctt)
@@ -189,7 +189,7 @@ def test_gemm_large_tile_epilogues_match_small_tile():
             ops.gemm_grouped(BPM_BF16, GEMM_NT, ps, seed=77)
             torch.cuda.synchronize()
             res[cfg] = [t.float().cpu() for t in (o1, o2, o3, o4, o5, cs)]
-    for cfg in (3, 2, 0, 5):
+    for cfg in (3, 2, 0, 5, 6):
         for i, nm in enumerate(("relu+drop CT", "gate CT", "heads 128", "heads 64", "accum f32", "colsum")):
             close(res[cfg][i], res[-2][i], 1e-2 if i < 4 else 2e-4, f"cfg {cfg} {nm}")
         assert ((res[cfg][0] == 0) == (res[-2][0] == 0)).all(), "dropout / relu zero pattern must be identical"
@@ -1108,3 +1108,35 @@ def test_gemm_skinny_rows(dtype, variant, M, N, K):
     if heads is not None:
         want = ((rb * 0.5).reshape(2, M // 2, 12, N // 12)).permute(1, 2, 0, 3)      # [B, H, T, dh]
         close(heads[..., :N // 12], want, 2 * t, "head-major")
+
+
+@pytest.mark.parametrize("variant,M,N,K", [(GEMM_NT, 1000, 520, 328), (GEMM_NN, 1000, 520, 328), (GEMM_TN, 520, 1000, 1300),
+                                          (GEMM_NT, 4096, 768, 768), (GEMM_TN, 768, 3072, 4096)])
+def test_gemm_two_resident_config(variant, M, N, K):
+    """The 256 x 128 tile with 32-k stages (three stages = 72 KB, <= 128 registers: two workgroups per CU; picked for the
+    FFN weight gradients and the twelve-problem K / V projections) forced on ragged shapes -- rows past M, a k tail that
+    is not a whole stage, a column tail -- and on the model's shapes, all three operand arrangements, against fp64."""
+    from bpmult_amd import _lib
+    pad64 = lambda n: (n + 63) // 64 * 64
+    if variant == GEMM_TN:
+        A, Ar = to_ct(rnd(K, M, seed=21), BPM_BF16, pad64(M))
+        Bm, Br = to_ct(rnd(K, N, seed=22, scale=K ** -0.5), BPM_BF16, pad64(N))
+        ref = Ar.double().T @ Br.double()
+    else:
+        A, Ar = to_ct(rnd(M, K, seed=21), BPM_BF16, pad64(K))
+        if variant == GEMM_NT:
+            Bm, Br = to_ct(rnd(N, K, seed=22, scale=K ** -0.5), BPM_BF16, pad64(K))
+            ref = Ar.double() @ Br.double().T
+        else:
+            Bm, Br = to_ct(rnd(K, N, seed=22, scale=K ** -0.5), BPM_BF16)
+            ref = Ar.double() @ Br.double()
+    base = rnd(M, N, seed=24).to(DEV)
+    out, acc = torch.full((M, N), float("nan"), device=DEV), base.clone()
+    ps = [ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N, flags=ops.F_KPAD),
+          ops.gemm_problem(A, Bm, acc, M, N, K, A.shape[1], Bm.shape[1], N, flags=ops.F_KPAD | F_ACCUM)]
+    with lab_library() as L:
+        _lib.check(L.bpm_debug_gemm_force(6), "force")
+        ops.gemm_grouped(BPM_BF16, variant, ps)
+        torch.cuda.synchronize()
+    close(out, ref, 2e-3, f"two-resident v{variant}")
+    close(acc, ref + base.cpu().double(), 2e-3, f"two-resident += v{variant}")

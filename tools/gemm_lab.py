@@ -21,8 +21,8 @@ from bpmult_amd.ops import (BPM_BF16, F_ACCUM, F_KPAD, F_RELU, GEMM_NN, GEMM_NT,
 
 DEV = "cuda"
 CT = torch.bfloat16
-NCFG = 6
-NAMES = {-1: "auto", -2: "tiled", 0: "128x128 4w", 1: "256x128 8w", 2: "256x256 8w", 3: "256x256 16w", 4: "128x128 ns3", 5: "320x256 8w"}
+NCFG = 7
+NAMES = {-1: "auto", -2: "tiled", 0: "128x128 4w", 1: "256x128 8w", 2: "256x256 8w", 3: "256x256 16w", 4: "128x128 ns3", 5: "320x256 8w", 6: "256x128 2/CU"}
 
 
 _LAB = None
