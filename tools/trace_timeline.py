@@ -14,9 +14,13 @@ def short(name):
     m = re.search(r"(gemm_tiled_kernel|gemm_dma_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|ln_fwd_kernel|"
                   r"ln_bwd_kernel|ln_fwd_vec_kernel|ln_bwd_vec_kernel|rows_cast_kernel|colsum_kernel|fold_bias_kernel|"
                   r"unfold_grads_kernel|embed_pos_fwd_kernel|embed_pos_bwd_kernel|pack_rows_\w+_kernel|gmu2_\w+_kernel|"
-                  r"pack_weights_kernel|xblock_fwd_kernel|tail_\w+_kernel|im2col1d_kernel|col2im1d_kernel|pool_\w+_kernel|adam_kernel)", name)
+                  r"pack_weights_kernel|xblock_fwd_kernel|tail_\w+_kernel|im2col1d_kernel|col2im1d_kernel|pool_\w+_kernel|adam_kernel|"
+                  r"adam_table_kernel|gemm_skinny_kernel|split_rows_kernel|add_n_kernel|zero_segments_kernel|signal_\w+_kernel)", name)
     if m:
         k = m.group(1)
+        if k == "gemm_skinny_kernel":
+            m2 = re.search(r"gemm_skinny_kernelI(?:DF16b|f)Lb([01])E", name)
+            return k + ("<NT>" if m2 and m2.group(1) == "1" else "<NN>")
         if k in ("gemm_tiled_kernel", "gemm_dma_kernel"):      # needs mangled names (rocprofv3 -M): the demangler garbles __bf16 templates
             m2 = re.search(r"gemm_tiled_kernelI(?:DF16b|f)Lb([01])ELb([01])E", name) or \
                 re.search(r"gemm_tiled_kernel<[^,]+, (true|false), (true|false)", name) or \
