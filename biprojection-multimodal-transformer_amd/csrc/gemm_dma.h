@@ -350,11 +350,16 @@ void gemm_dma_kernel(const Group grp) {
         const char* iy = ix + SX::IMG_BYTES;
         auto step = [&](auto KS) {
             constexpr int ks = decltype(KS)::value;
+            // (two-resident configuration with the bias column sums, 128 registers: the second pair of Y fragments is read
+            // behind the first half of the MFMAs into the same registers -- with all four live it spilled 13 of them: 253 us
+            // for the attention weight gradients, 148 so, the same as the 256 x 256 tile.  Without the column sums the late
+            // reads cost: FFN weight gradients 279 -> 320 us, so those keep all four fragments up front)
+            constexpr bool YLATE = DKT == 32 && XS;
             bf16x8 fx[TMW], fy[4];
 #pragma unroll
             for (int b = 0; b < TMW; ++b) fx[b] = SX::frag(ix, wm * WROWS + 16 * b, ks, lane);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) fy[a] = SY::frag(iy, wn * 64 + 16 * a, ks, lane);
+            for (int a = 0; a < (YLATE ? 2 : 4); ++a) fy[a] = SY::frag(iy, wn * 64 + 16 * a, ks, lane);
             if constexpr (XS) {
                 if (do_xs && seg_of(kt) != 1) {            // (X3: segments 0 and 2 carry X's hi and lo planes; segment 1 repeats hi)
                     bf16x8 one;
@@ -382,10 +387,14 @@ void gemm_dma_kernel(const Group grp) {
                 if constexpr (KSPS == 2) part(kt + NS - 1, nbuf, std::integral_constant<int, 2 * ks + 1>{});
                 else { part(kt + NS - 1, nbuf, std::integral_constant<int, 2>{}); part(kt + NS - 1, nbuf, std::integral_constant<int, 3>{}); }
             }
+            if constexpr (YLATE) {
+#pragma unroll
+                for (int a = 2; a < 4; ++a) fy[a - 2] = SY::frag(iy, wn * 64 + 16 * a, ks, lane);
+            }
 #pragma unroll
             for (int a = 2; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < TMW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TMW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[YLATE ? a - 2 : a], fx[b], acc[a][b], 0, 0, 0);
         };
         if (!(BPM_DMA_ABLATE & 1)) {
             step(std::integral_constant<int, 0>{});
