@@ -509,8 +509,7 @@ class _Trunk:
             rows2 += [(src, t) for t in gmu_terms[src] if t.numel() != d1[src].numel()]
             sums.append(ops.addn_problem(d1[src], [t.view(d1[src].shape) for t in full] + [gk, gv]))
         ops.add_n(sums)
-        for src, t in rows2:
-            d1[src].index_add_(0, self.idx[LEVEL1[src][0]], t.view(2, self.B, self.d))
+        self._add_rows2([(d1[src], t) for src, t in rows2])
         dq1, dk1, dv1 = self.plan1.backward([d1[n] for n in LEVEL1], self._layer_hook("level1"), stores=stores)
         acc: Dict[str, List[torch.Tensor]] = {"l": [], "a": [], "v": []}
         for (n, (q, kv, _)), gq, gk, gv in zip(LEVEL1.items(), dq1, dk1, dv1):
@@ -520,14 +519,40 @@ class _Trunk:
         for (n, (q, src, _)), gq in zip(LEVEL2.items(), dq2):
             (small if gq.shape[0] != self.N[q] else acc)[q].append(gq)
         ops.add_n([ops.addn_problem(self.dpx[k], terms) for k, terms in acc.items()])
-        for k in acc:
-            for gq in small[k]:
-                self.dpx[k].index_add_(0, self.idx[k], gq)
+        self._add_rows2([(self.dpx[k], gq) for k in acc for gq in small[k]])
         res = self.conv_backward(seed, need_dx)
         self._ready("proj")
         if attach:
             st.end_backward()
         return res
+
+    def _add_rows2(self, pairs) -> None:
+        """dst[0] += t[0], dst[N-1] += t[1] for (dst [N, B, d], t [2, B, d]) pairs -- the two-row terms of the pruned
+        schedule -- as ONE grouped bpm_add_n launch over the row blocks (in place, terms added in list order: the result
+        index_add_ per term gave, which was 18 launches of 5 us and as many dependency gaps per step at hidden 768)."""
+        if not pairs:
+            return
+        B, d = self.B, self.d
+        if (B * d) % 4:                                   # row blocks not 16-byte aligned: the torch path
+            for dst, t in pairs:
+                dst[0] += t.view(2, B, d)[0]
+                dst[-1] += t.view(2, B, d)[1]
+            return
+        terms: Dict[int, list] = {}
+        for dst, t in pairs:
+            t = t.view(2, B, d)
+            for j, r in ((0, 0), (1, dst.shape[0] - 1)):
+                terms.setdefault((dst.data_ptr(), r), [dst[r]]).append(t[j])
+        while terms:                                      # at most 8 inputs per problem (the destination among them), and a
+            probs = []                                    # destination once per launch
+            for key in list(terms):
+                out, ins = terms[key][0], terms[key][1:]
+                probs.append(ops.addn_problem(out, [out] + ins[:7]))
+                if len(ins) > 7:
+                    terms[key] = [out] + ins[7:]
+                else:
+                    del terms[key]
+            ops.add_n(probs)
 
     # -- captured launch sequences (hipGraph) ---------------------------------------
     # The ~420 launches of a step are the same every step for a given (mode, input lengths): captured once per key and

@@ -697,7 +697,7 @@ def test_text_encoder_from_local_directory_through_the_hip_trunk(tmp_path):
     feats = m_tok.enc(txt, mask, seg).detach()
     assert feats.shape == (2, 17, 32)
     ref = m_feat(feats, None, None, img, aud)
-    assert float((logits - ref).abs().max()) <= 1e-5
+    assert float((logits - ref).detach().abs().max()) <= 1e-5
     # the reference's batch tuple (helpers.py:129-133) through training.model_forward (train.py:283-338)
     loss, out, _ = TR.model_forward(m_tok, torch.nn.BCEWithLogitsLoss(), (txt, seg, mask, img, tgt, aud), "mmtrvat")
     assert float((out - ref).abs().max()) <= 1e-5

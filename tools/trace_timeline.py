@@ -2,7 +2,10 @@
 """Summarise a rocprofv3 kernel_trace.csv: for the last full bench step, the time each kernel family
 spends per queue, the union busy time, and the idle gaps on the main queue.
 
-  python tools/trace_timeline.py gpurun_out/prof/x_kernel_trace.csv [--step-marker embed_pos_fwd]
+  python tools/trace_timeline.py gpurun_out/prof/x_kernel_trace.csv [--list]
+
+--list: additionally every launch of that step in start order -- ms into the step, queue, duration, the idle time of the
+union timeline in front of it (where nothing at all was running) and grid / workgroup size.
 """
 import csv
 import re
@@ -94,6 +97,16 @@ def main():
     print("largest single gaps (us, at ms into the step):")
     for g, at, a_, b_ in sorted(gaps, reverse=True)[:8]:
         print(f"   {1e-3 * g:8.1f} us at {at:7.3f} ms   {a_} -> {b_}")
+    if "--list" in sys.argv:
+        qn = {q: i for i, q in enumerate(sorted(per, key=lambda q: -qbusy[q]))}
+        print("launches in start order: ms into the step | queue | us | idle in front (us) | kernel | grid / workgroup")
+        cur_e = int(step[0]["Start_Timestamp"])
+        for r in step:
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            idle = max(0, st - cur_e)
+            cur_e = max(cur_e, en)
+            print(f"   {1e-6 * (st - t0):8.3f}  q{qn[r['Queue_Id']]}  {1e-3 * (en - st):8.1f}  {1e-3 * idle:6.1f}  {short(r['Kernel_Name']):40s} "
+                  f"{r.get('Grid_Size_X', '?')}/{r.get('Workgroup_Size_X', '?')}")
     small = sum(en - st for st, en, k in ev if en - st < 30000)
     print(f"kernels shorter than 30 us: {sum(1 for st, en, k in ev if en - st < 30000)} launches, {1e-6 * small:.3f} ms of queue time")
 
