@@ -23,7 +23,7 @@ ARCH = "gfx950"
 PROF_KINDS = {"gemm_nt": 0, "gemm_nn": 1, "gemm_tn": 2, "attn_fwd": 3, "attn_bwd_dq": 4, "attn_bwd_dkv": 5,
               "gemm_dma_nt": 13, "gemm_dma_nn": 14, "gemm_dma_tn": 15}      # gemm_*: the 128 x 64 kernel; gemm_dma_*: the LDS-DMA kernel
 
-ABI_VERSION = 2                   # == BPM_ABI_VERSION of include/bpmult_hip.h; lib() refuses any other library
+ABI_VERSION = 3                   # == BPM_ABI_VERSION of include/bpmult_hip.h; lib() refuses any other library
 # -DBPM_LAB build: the same kernels plus the two process-global tuning hooks (bpm_debug_gemm_force / bpm_debug_attn_pair)
 # that tools/gemm_lab.py, tools/attn_lab.py and three kernel tests use; never loaded by the product path
 LAB_LIB_PATH = os.path.join(_HERE, "..", "build", "lab", "libbpmult_hip_lab.so")
@@ -32,6 +32,7 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
 F_ACCUM, F_RELU, F_ATOMIC, F_KPAD, F_BACKGROUND = 1, 2, 4, 8, 16     # F_KPAD = BPM_GEMM_KPAD_ZERO
 F_A_OVERLAP, F_B_OVERLAP = 32, 64                                     # BPM_GEMM_A_OVERLAP / _B_OVERLAP
+F_CT_NARROW = 128                                                     # BPM_GEMM_CT_NARROW
 LN_OUT_F32 = 2
 MAX_GROUP = 18
 SEED_INDIRECT = 1 << 63          # seed = SEED_INDIRECT | device address of a uint64 (include/bpmult_hip.h)
@@ -123,7 +124,8 @@ class AttnProblem(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("S", C.c_int),
                 ("dh", C.c_int), ("dhp", C.c_int), ("mask_off", C.c_int),
                 ("dq_scale", C.c_float), ("drop_p", C.c_float), ("drop_site", C.c_uint32),
-                ("q_pos0", C.c_int), ("q_stride", C.c_int)]
+                ("q_pos0", C.c_int), ("q_stride", C.c_int),
+                ("dS", C.c_void_p), ("Pd", C.c_void_p), ("xs_b", C.c_int), ("xs_h", C.c_int), ("xs_q", C.c_int)]
 
 
 class PackProblem(C.Structure):
@@ -196,6 +198,12 @@ class AddnProblem(C.Structure):
     _fields_ = [("out", C.c_void_p), ("src", C.c_void_p * 8), ("n_in", C.c_int), ("count", C.c_size_t)]
 
 
+class ExpandProblem(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("dO", C.c_void_p), ("qexp", C.c_void_p), ("dOexp", C.c_void_p), ("Pd", C.c_void_p),
+                ("dbias", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("S", C.c_int), ("dh", C.c_int),
+                ("dhp", C.c_int), ("ld", C.c_int)]
+
+
 class TailDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("d", C.c_int), ("n", C.c_int), ("C", C.c_int), ("N", C.c_int * 3),
                 ("top", C.c_void_p * 3), ("mid", C.c_void_p * 3), ("extra", C.c_void_p),
@@ -239,6 +247,7 @@ SIGNATURES = {
     "bpm_ln_bwd_ws_bytes": [_I, _I],
     "bpm_rows_cast": [_I, C.POINTER(CastProblem), _I, _U64, _P],
     "bpm_add_n": [C.POINTER(AddnProblem), _I, _P],
+    "bpm_expand_heads": [_I, C.POINTER(ExpandProblem), _I, _P],
     "bpm_split_rows": [C.POINTER(SplitProblem), _I, _P],
     "bpm_gmu2_fwd": [C.POINTER(GmuProblem), _I, _I, _P],
     "bpm_gmu2_bwd": [_I, C.POINTER(GmuProblem), _I, _I, _P],

@@ -82,6 +82,8 @@ struct AProb {
     int qpos0, qstride;   // query row i sits at time qpos0 + i*qstride (mask rule only)
     float dq_scale;
     DropCfg drop;
+    char* dS; char* Pd;       // dQ pass, optional: dS and the dropped probabilities, element (b, h, i, j) at b xs_b + h xs_h + i xs_q + j
+    int xs_b, xs_h, xs_q;
     int blk0, nblk;     // block prefix / blocks per (b,h)
     int pair;           // workgroups take two blocks (b, nblk - 1 - b) instead of one
 };
@@ -374,7 +376,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 // ---------------------------------------------------------------------------
 // backward, dQ (and delta = rowsum(dO * O))
 // ---------------------------------------------------------------------------
-template <typename CT, int DHP>
+// XP: also write dS and the dropped probabilities (AProb::dS / Pd) -- the few-query-row groups of the engine (level 2 under
+// dead-row elimination) continue from those instead of dK / dV: with two query rows dK and dV have rank two per head, and
+// every key / value-side product factors through [rows, S] matrices (engine.EncoderGroupPlan, "low-rank key side").
+// A separate instantiation: the stores would cost the T = S = 512 launches registers.
+template <typename CT, int DHP, bool XP>
 BPM_DEV void attn_bwd_dq_block(const AProb& P, const DropCfg& drop, char* smem, const int bh, const int qb) {
     typedef Cfg<CT, DHP> C;
     typedef typename Tr<CT>::frag frag;
@@ -479,6 +485,23 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, const DropCfg& drop, char* smem, 
                 for (int r = 0; r < 4; ++r) p4[r] = fast_exp2(e4[r]);
                 const f32x4 dm4 = f32x4{dm[0], dm[1], dm[2], dm[3]};
                 ds[nn] = p4 * (dp * dm4 - delta);
+                if constexpr (XP) {
+                    const int j0 = jb + 16 * n;                  // four consecutive keys (S % 4 == 0: all four or none exist)
+                    if (P.dS && q < P.T && j0 < P.S) {
+                        const size_t off = (size_t)b * P.xs_b + (size_t)h * P.xs_h + (size_t)q * P.xs_q + j0;
+                        const f32x4 pd = p4 * dm4;
+                        if constexpr (C::SZ == 4) {
+                            *(f32x4*)((float*)P.dS + off) = ds[nn];
+                            *(f32x4*)((float*)P.Pd + off) = pd;
+                        } else {
+                            bf16x4 o, w;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)ds[nn][r]; w[r] = (bf16_t)pd[r]; }
+                            *(bf16x4*)((bf16_t*)P.dS + off) = o;
+                            *(bf16x4*)((bf16_t*)P.Pd + off) = w;
+                        }
+                    }
+                }
             }
             // dQ^T += K^T dS^T
             if (BPM_ATTN_SETPRIO) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO + 1);
@@ -499,7 +522,7 @@ BPM_DEV void attn_bwd_dq_block(const AProb& P, const DropCfg& drop, char* smem, 
 // (dK / dV) tiles, so every pair carries the same work, and the per-block lead-in (operand loads, first tile, result
 // store: ~6 us of latency that four resident workgroups per CU cannot hide) is paid half as often.  Measured on MI355X,
 // 576 heads of 64, T = S = 512, masked: see DESIGN.md section 5 (attention).
-template <typename CT, int DHP>
+template <typename CT, int DHP, bool XP>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_waves<CT>(1, DHP), attn_waves<CT>(1, DHP)))) void attn_bwd_dq_kernel(const AGroup grp) {
     typedef Cfg<CT, DHP> C;
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * C::STRIDE];
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(attn_w
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (pass && second == first) break;
-        attn_bwd_dq_block<CT, DHP>(P, drop, smem, bh, pass ? second : first);
+        attn_bwd_dq_block<CT, DHP, XP>(P, drop, smem, bh, pass ? second : first);
     }
 }
 
@@ -711,6 +734,11 @@ int fill(AGroup& g, const bpm_attn_problem* probs, int nprob, int blocks_over_S,
         p.qpos0 = q.q_pos0; p.qstride = q.q_stride > 0 ? q.q_stride : 1;
         if ((long)p.qpos0 + (long)(q.T - 1) * p.qstride > (1l << 28)) return BPM_ERR_ARG;
         p.dq_scale = q.dq_scale;
+        p.dS = (char*)q.dS; p.Pd = (char*)q.Pd; p.xs_b = q.xs_b; p.xs_h = q.xs_h; p.xs_q = q.xs_q;
+        if (q.dS || q.Pd) {       // both, whole 4-key groups, 4-element-aligned rows that do not run into each other
+            if (!q.dS || !q.Pd || (q.S & 3) || ((q.xs_b | q.xs_h | q.xs_q) & 3) || q.xs_b < 0 || q.xs_h < 0 || q.xs_q < q.S) return BPM_ERR_ARG;
+            if ((((uintptr_t)q.dS | (uintptr_t)q.Pd) & 15) != 0) return BPM_ERR_ALIGN;
+        }
         p.drop = bpm_make_drop(q.drop_p, seed, q.drop_site);
         p.nblk = ((blocks_over_S ? q.S : q.T) + 63) / 64;
         p.blk0 = blk;
@@ -758,7 +786,8 @@ int dispatch(int which, int dhp, const AGroup& g, int total, hipStream_t s) {
 #define BPM_ATTN_CASE(D)                                                                                        \
     case D:                                                                                                     \
         if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<CT, D>), grid, block, 0, s, g);                     \
-        else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, D>), grid, block, 0, s, g);             \
+        else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, D, false>), grid, block, 0, s, g);      \
+        else if (which == 3) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, D, true>), grid, block, 0, s, g);       \
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, D>), grid, block, 0, s, g);                            \
         break;
     switch (dhp) {
@@ -812,7 +841,10 @@ static int attn_bwd_parts(int dtype, const bpm_attn_problem* probs, int nprob, u
     const double w = 4.0 * useful_pair_flops(probs, nprob);
     if (parts & 1) {
         BpmProfScope prof(BPM_K_ATTN_BWD_DQ, s, w, attn_bytes(probs, nprob, dtype == BPM_BF16 ? 2 : 4, 1));
-        rc = dtype == BPM_BF16 ? dispatch<bf16_t>(1, probs[0].dhp, g, total, s) : dispatch<float>(1, probs[0].dhp, g, total, s);
+        bool xp = false;
+        for (int i = 0; i < nprob; ++i) xp = xp || probs[i].dS != nullptr;
+        const int which = xp ? 3 : 1;
+        rc = dtype == BPM_BF16 ? dispatch<bf16_t>(which, probs[0].dhp, g, total, s) : dispatch<float>(which, probs[0].dhp, g, total, s);
         if (rc) return rc;
     }
     if (parts & 2) {

@@ -189,7 +189,7 @@ BPM_DEV void epilogue_tile(const Prob& P, const DropCfg& drop, bool lead, int m,
             }
         }
     } else if (P.out_kind == BPM_OUT_CT) {
-        const int nvalid = min(4, P.ldc - nb);   // pad columns [N, ldc) get zeros
+        const int nvalid = min(4, ((P.flags & BPM_GEMM_CT_NARROW) ? P.N : P.ldc) - nb);   // pad columns [N, ldc) get zeros
         if (nvalid > 0) store_ct4<CT>(P.C, (size_t)m * P.ldc + nb, v, nvalid);
     } else {  // BPM_OUT_HEADS: m = t*B + b, n = h*dh + c  ->  [B,H,T,dhp]
         const int tt = m / P.hB, bb = m % P.hB;
@@ -321,7 +321,7 @@ BPM_DEV void epi_fast_apply(const Prob& P, const DropCfg& drop, int mrow, int nb
         if (f32out) {
             if (valid) *(f32x4*)((float*)P.C + e.offc + nb) = x;
         } else if (P.out_kind == BPM_OUT_CT) {
-            if (e.ok && nb < P.ldc) {                   // pad columns [N, ldc) receive zeros
+            if (e.ok && nb < ((P.flags & BPM_GEMM_CT_NARROW) ? P.N : P.ldc)) {   // pad columns [N, ldc) receive zeros
                 if (!valid) x = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (sizeof(CT) == 4) *(f32x4*)((float*)P.C + e.offc + nb) = x;
                 else { bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3]; *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o; }
@@ -1092,7 +1092,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         p.hB = q.heads_B; p.hH = q.heads_H; p.hT = q.heads_T; p.hdh = q.heads_dh; p.hdhp = q.heads_dhp;
         if (q.out_kind == BPM_OUT_HEADS && (q.heads_B < 1 || q.heads_dh < 1 || q.heads_H * q.heads_dh != q.N)) return BPM_ERR_ARG;
         const int ntiles = (q.N + bn_tile - 1) / bn_tile;
-        if (q.out_kind == BPM_OUT_CT && ntiles * bn_tile < q.ldc) return BPM_ERR_ARG;
+        if (q.out_kind == BPM_OUT_CT && !(q.flags & BPM_GEMM_CT_NARROW) && ntiles * bn_tile < q.ldc) return BPM_ERR_ARG;
         p.tile0 = tile;
         p.tiles_m = (q.M + bm_tile - 1) / bm_tile;
         p.tiles_n = ntiles;

@@ -144,7 +144,7 @@ BPM_DEV void wide_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, co
         if (f32out) {
             if (valid) *(f32x4*)((float*)P.C + e.offc + nb) = x;
         } else if (P.out_kind == BPM_OUT_CT) {
-            if (e.ok && nb < P.ldc) {                   // pad columns [N, ldc) receive zeros
+            if (e.ok && nb < ((P.flags & BPM_GEMM_CT_NARROW) ? P.N : P.ldc)) {   // pad columns [N, ldc) receive zeros
                 if (!valid) x = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (sizeof(OT) == 4) *(f32x4*)((float*)P.C + e.offc + nb) = x;
                 else { bf16x4 o; o[0] = (bf16_t)x[0]; o[1] = (bf16_t)x[1]; o[2] = (bf16_t)x[2]; o[3] = (bf16_t)x[3]; *(bf16x4*)((bf16_t*)P.C + e.offc + nb) = o; }

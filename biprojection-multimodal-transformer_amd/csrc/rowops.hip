@@ -1247,6 +1247,75 @@ extern "C" int bpm_split_rows(const bpm_split_problem* q, int n, void* stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// expand_heads: head-major q / dO [B, H, T, dhp] -> block rows [(h*T + t)*B + b, ld] whose columns [h dh, (h+1) dh) hold
+// the head's vector and all others zero.  With these the per-head products of the low-rank key side (a handful of query
+// rows: engine.EncoderGroupPlan) are plain grouped GEMMs over all heads at once: Qexp W_k' = every head's query through
+// its block of W_k', Qexp^T U = every head's block of the weight gradient.  Also the value-projection bias gradient,
+// sum_{b,t} rowsum(Pd[b,h,t,:]) dO[b,h,t,:] (the column sums of dV = Pd^T dO; rowsum(Pd) != 1 under attention dropout).
+// One workgroup per (problem, head); its four waves take the head's T*B rows in turn, the bias sums are combined in a
+// fixed order (no atomics: bitwise reproducible) and WRITTEN (the launch owns dbias).
+// ---------------------------------------------------------------------------
+struct ExpP { const void* q; const void* dO; void* qexp; void* dOexp; const void* Pd; float* dbias; int B, H, T, S, dh, dhp, ld; };
+
+template <typename CT>
+__global__ __launch_bounds__(NT) void expand_heads_kernel(const Grp<ExpP> grp) {
+    __shared__ float red[NT / 64][128];
+    unsigned bid = blockIdx.x, nblk;
+    const ExpP& P = pick(grp, bid, nblk);
+    const int h = (int)bid, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c0 = h * P.dh;
+    float acc0 = 0.f, acc1 = 0.f;                         // bias sums of columns lane, lane + 64 of this head
+    for (int tb = wv; tb < P.T * P.B; tb += NT / 64) {
+        const int t = tb / P.B, b = tb - t * P.B;
+        const size_t r = (size_t)(h * P.T + t) * P.B + b;
+        const CT* qrow = (const CT*)P.q + ((size_t)(b * P.H + h) * P.T + t) * P.dhp;
+        const CT* drow = (const CT*)P.dO + ((size_t)(b * P.H + h) * P.T + t) * P.dhp;
+        for (int c = lane; c < P.ld; c += 64) {
+            const bool in = c >= c0 && c < c0 + P.dh;
+            put<CT>(P.qexp, r * P.ld + c, in ? Tr<CT>::to_f(qrow[c - c0]) : 0.f);
+            put<CT>(P.dOexp, r * P.ld + c, in ? Tr<CT>::to_f(drow[c - c0]) : 0.f);
+        }
+        if (P.dbias) {
+            float rs = 0.f;
+            const CT* prow = (const CT*)P.Pd + r * P.S;
+            for (int j = lane; j < P.S; j += 64) rs += Tr<CT>::to_f(prow[j]);
+            rs = wave_sum(rs);
+            if (lane < P.dh) acc0 += rs * Tr<CT>::to_f(drow[lane]);
+            if (lane + 64 < P.dh) acc1 += rs * Tr<CT>::to_f(drow[lane + 64]);
+        }
+    }
+    if (!P.dbias) return;                                 // uniform per block
+    red[wv][lane] = acc0; red[wv][lane + 64] = acc1;
+    __syncthreads();
+    for (int j = threadIdx.x; j < P.dh; j += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) s += red[w][j];
+        P.dbias[c0 + j] = s;
+    }
+}
+
+extern "C" int bpm_expand_heads(int dtype, const bpm_expand_problem* q, int n, void* stream) {
+    if (!q || n < 1 || n > BPM_MAX_GROUP || (dtype != BPM_F32 && dtype != BPM_BF16)) return BPM_ERR_ARG;
+    Grp<ExpP> g;
+    g.n = n; g.blk0[0] = 0; g.seedp = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const bpm_expand_problem& s = q[i];
+        if (!s.q || !s.dO || !s.qexp || !s.dOexp || s.B < 1 || s.H < 1 || s.T < 1 || s.dh < 1 || s.dh > s.dhp || s.dh > 128 ||
+            s.ld < s.H * s.dh || (s.dbias && (!s.Pd || s.S < 1)))
+            return BPM_ERR_ARG;
+        ExpP& p = g.p[i];
+        p.q = s.q; p.dO = s.dO; p.qexp = s.qexp; p.dOexp = s.dOexp; p.Pd = s.Pd; p.dbias = s.dbias;
+        p.B = s.B; p.H = s.H; p.T = s.T; p.S = s.S; p.dh = s.dh; p.dhp = s.dhp; p.ld = s.ld;
+        g.blk0[i + 1] = g.blk0[i] + (unsigned)s.H;
+    }
+    if (dtype == BPM_BF16) hipLaunchKernelGGL(expand_heads_kernel<bf16_t>, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(expand_heads_kernel<float>, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
+    BPM_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int bpm_add_n(const bpm_addn_problem* q, int n, void* stream) {
     if (!q || n < 1 || n > BPM_MAX_GROUP) return BPM_ERR_ARG;
     Grp<AddP> g;

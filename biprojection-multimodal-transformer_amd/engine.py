@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
-from ._lib import (BPM_BF16, AdamSeg, AddnProblem, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
+from ._lib import (BPM_BF16, AdamSeg, AddnProblem, ExpandProblem, F_CT_NARROW, F_ACCUM, F_BACKGROUND, F_KPAD, F_RELU, GEMM_NN, GEMM_NT, GEMM_TN, OUT_CT, OUT_HEADS,
                    AttnProblem, CastProblem, FoldDesc, GemmProblem, LnProblem, PackDesc,
                    UnfoldDesc)
 from .ops import pad32
@@ -430,6 +430,8 @@ _side_streams: Dict[Tuple[int, int, bool], "torch.cuda.Stream"] = {}
 # 768 every GEMM workgroup owns a CU for 50-300 us, the side stream's weight gradients are a third of the step's work,
 # and starving them only lengthens the tail (37.97 ms/step low, 37.53 normal).
 _SIDE_PRIORITY_ENV = os.environ.get("BPMULT_SIDE_PRIORITY", "auto")
+# Low-rank key side for groups with a handful of query time steps (EncoderGroupPlan._lowrank; "0": dK / dV as everywhere else)
+_LOWRANK = os.environ.get("BPMULT_LOWRANK", "1") != "0"
 # (Measured in round 3 and removed: a side stream restricted to 160-224 CUs by hipExtStreamCreateWithCUMask, so that the
 # main stream's row kernels never queue behind weight-gradient workgroups: 47-51 ms/step against 32.5.  Also without
 # effect: d(LayerNorm output) written as bf16 by the data-gradient GEMMs and read as bf16 by the LayerNorm backward --
@@ -473,6 +475,18 @@ class EncoderGroupPlan:
             raise ValueError("embed_dim must be divisible by num_heads")
         self.dh = d // H
         self.dhp = dhp_for(self.dh)
+        # LOW-RANK KEY SIDE.  With T query time steps dK = dS^T Q and dV = Pd^T dO have rank T per (batch element, head), and
+        # every key / value-side product of the backward factors through the [H T, S] matrices dS, Pd (written by the dQ
+        # pass) instead of the [S B, d] matrices dK, dV:
+        #   W_k' gradient  = Qexp^T (dS khat)           (was dK^T khat: d x d x S B -- now H T B x S x d, then d x d x H T B)
+        #   d(khat)        = sum_layers dS^T (Qexp W_k') (was dK W_k' over K = layers d -- now K = layers H T)
+        # and the same with Pd, dOexp, vhat, W_v' for the value side (Qexp / dOexp: the heads' vectors in their own column
+        # block of otherwise-zero rows, bpm_expand_heads, so that all heads travel in one product).  Level 2 under dead-row
+        # elimination has T = 2: at hidden 768 this removes 1.5 of the step's 19.4 ms (the key / value weight gradients over
+        # 4096 rows, the merged K = 6144 data gradient, the dK / dV pass).  Equal to the dK / dV route in real arithmetic; the
+        # roundings differ (dS instead of dK is rounded to CT), fixtures F7 / F9 / F11 hold both.  Crossmodal groups only.
+        self._lowrank = (_LOWRANK and not cfg.biprojection and all(e.T * H * 4 <= d and e.S % 4 == 0 for e in self.encs)
+                         and self.dh <= 128)
         self.ld, self.ld4 = pad32(d), pad32(4 * d)
         self.scale = self.dh ** -0.5
         dev, ct = store.device, ops.ct_torch(self.dtype)
@@ -514,7 +528,18 @@ class EncoderGroupPlan:
             # end of backward (dK_i / dV_i of every layer are kept side by side in dkall / dvall) instead of L products
             # accumulating into the same fp32 [Rk, d] tensor (8 x 300 MB of read-modify-write per level at hidden 768)
             b["Gk"], b["Gv"] = z(Rk, d), z(Rk, d)
-            b["dkall"], b["dvall"] = z(Rk, L * self.ld, dt=ct), z(Rk, L * self.ld, dt=ct)
+            if self._lowrank:
+                HT, Sp = H * e.T, (e.S + 63) // 64 * 64
+                b["Sp"] = Sp
+                # dS / Pd of every layer, [layer][h*T + t][b][key] with zero key padding (never written); the same row
+                # order (h*T + t)*B + b for the expanded head rows and everything computed from them
+                b["dSall"], b["Pdall"] = z(L, HT, B, Sp, dt=ct), z(L, HT, B, Sp, dt=ct)
+                b["qkall"], b["daall"] = z(L, HT * B, self.ld, dt=ct), z(L, HT * B, self.ld, dt=ct)
+                for nm in ("qexp", "doexp", "U", "Av"):
+                    b[nm] = [z(HT * B, self.ld, dt=ct) for _ in range(2)]
+                b["dkall"] = b["dvall"] = None
+            else:
+                b["dkall"], b["dvall"] = z(Rk, L * self.ld, dt=ct), z(Rk, L * self.ld, dt=ct)
             b["dWf"] = [z(2 * d, d) for _ in range(L)]              # folded K/V weight gradients (per backward)
             b["dbf"] = carve(L, 2 * d)                              # folded K/V bias gradients (column sums)
             # per-layer activations: shape(i) -- query-side tensors follow Rl / Tl, key / value-side ones stay full
@@ -736,6 +761,8 @@ class EncoderGroupPlan:
             fn(s[1], s[2], s[3], seed)
         elif fn in (ops.attn_fwd, ops.attn_bwd, ops.attn_bwd_dq, ops.attn_bwd_dkv, ops.rows_cast):
             fn(s[1], s[2], seed)
+        elif fn is ops.expand_heads:
+            fn(s[1], s[2])
         elif fn is ops.ln_fwd:
             fn(s[1], s[2], s[3])
         elif fn is ops.ln_bwd:
@@ -848,6 +875,8 @@ class EncoderGroupPlan:
             wg_att, dg_out, att, dg_q, lnq = [], [], [], [], []
             s_cast0, s_dgout0, s_att0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], []
             s_dgq, s_scatter = [], []                 # tail_rows (last layer): d(LN0 rows {0, T-1}) and the scatter back to [R, d]
+            lr = self._lowrank
+            lr_exp, lr_qk, lr_u = [], [], []          # low-rank key side: head expansion, Qexp W' products, dS khat / Pd vhat
             pre_ffn, pre_att = [], []                 # bf16x3: operands of the weight gradients whose split image already exists
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -867,7 +896,7 @@ class EncoderGroupPlan:
                 par = i & 1
                 dh1, dy, dq, dao, delta = (b[n][par] for n in ("dh1", "dy", "dq", "dao", "delta"))
                 ldk = c.layers * ld                       # layer i's dK / dV: column block i of dkall / dvall
-                dk, dv = b["dkall"][:, i * ld:(i + 1) * ld], b["dvall"][:, i * ld:(i + 1) * ld]
+                dk, dv = (None, None) if lr else (b["dkall"][:, i * ld:(i + 1) * ld], b["dvall"][:, i * ld:(i + 1) * ld])
                 dyf = b["dyf"][i % 3]
                 # hand-off to the next layer down (i-1): its FFN-output gradient dyf = dropmask(dx) and fc2.bias
                 # gradient are produced by whichever LayerNorm backward finishes this layer's dx
@@ -876,7 +905,7 @@ class EncoderGroupPlan:
                 if c.biprojection:
                     dy0, dqs, dks, dvs = (b[n][par] for n in ("dy0", "dqs", "dks", "dvs"))
                 pre_ffn += [dyf, dh1, b["h1"][i], b["xn2"][i]]
-                pre_att += [dy, dq, b["ao"][i], b["xq"][i] if c.biprojection else b["xn"][i], b["khat"], b["vhat"]]
+                pre_att += [dy, dq, b["ao"][i], b["xq"][i] if c.biprojection else b["xn"][i]] + ([] if lr else [b["khat"], b["vhat"]])
                 # ---- FFN
                 wg_ffn.append(ops.gemm_problem(dyf, b["h1"][i], GP("fc2.weight"), d, 4 * d, Rq, ld, ld4, 4 * d,
                                                flags=ACC1))
@@ -896,10 +925,15 @@ class EncoderGroupPlan:
                                                flags=ACC1))
                 dg_out.append(ops.gemm_problem(dy, st.sptr(wo), dao, Rq, d, d, ld, ld, 0, out_kind=OUT_HEADS,
                                                heads=(B, H, Tq, dh, dhp)))
+                lrx = {}
+                if lr:
+                    HT, Sp = H * Tq, b["Sp"]
+                    rows = HT * B                        # row (h*T + t)*B + b everywhere below
+                    lrx = dict(dS=b["dSall"][i], Pd=b["Pdall"][i], xs=(Sp, Tq * B * Sp, B * Sp))
                 att.append(ops.attn_problem(b["qh"][i], b["kh"][i], b["vh"][i], b["ao"][i], ld, b["lse"][i], B, H, Tq, e.S, dh, dhp,
                                             self._mask_off(e.T_full or e.T, e.S), dO=dao, delta=delta, dQ=dq, lddq=ld,
                                             dK=dk, lddk=ldk, dV=dv, lddv=ldk, dq_scale=self.scale,
-                                            drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN), **qpos))
+                                            drop_p=pr(e.attn_dropout), drop_site=site(e.enc_id, i, S_ATTN), **qpos, **lrx))
                 ipb_g = self._pn(e, i, "self_attn.in_proj_bias")
                 # query projection: gradients go straight to the parameters.  Key / value projections ran with the
                 # LayerNorm folded in: their bias column sums and weight gradients (against khat / vhat) land in
@@ -908,8 +942,24 @@ class EncoderGroupPlan:
                 q_src = b["xq"][i] if c.biprojection else b["xn"][i]
                 wg_att.append(ops.gemm_problem(dq, q_src, st.gptr(ipw, 0), d, d, Rq, ld, ld, d, flags=ACC1,
                                                colsum_a=st.gptr(ipb_g, 0)))
-                wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][:d]))
-                wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][d:]))
+                if lr:
+                    qexp, doexp, U, Av = (b[n][par] for n in ("qexp", "doexp", "U", "Av"))
+                    # heads' q / dO vectors as block rows; the folded value-bias gradient = sum rowsum(Pd) dO (the folded key
+                    # bias gets none: the rows of dS sum to zero -- dbf's key half stays at the zero every backward starts from)
+                    lr_exp.append(ops.expand_problem(b["qh"][i], dao, qexp, doexp, B, H, Tq, dh, dhp, ld, Pd=b["Pdall"][i], S=Sp,
+                                                     dbias=b["dbf"][i][d:]))
+                    for src, stack, dst in ((qexp, KSTACK, b["qkall"][i]), (doexp, VSTACK, b["daall"][i])):
+                        lr_qk.append(ops.gemm_problem(src, st.sptr(e.prefix + stack, i * ld * ld), dst, rows, d, d, ld, ld, ld,
+                                                      out_kind=OUT_CT))
+                    for bb in range(B):                  # per batch element: [H T, S] x [S, d] (rows of batch element bb: stride B)
+                        for mat, hat_, dst in ((b["dSall"][i], b["khat"], U), (b["Pdall"][i], b["vhat"], Av)):
+                            lr_u.append(ops.gemm_problem(mat[0, bb], hat_[bb], dst[bb], HT, d, e.S, B * Sp, B * ld, B * ld,
+                                                         out_kind=OUT_CT, flags=F_CT_NARROW))
+                    wg_att.append(ops.gemm_problem(qexp, U, b["dWf"][i][:d], d, d, rows, ld, ld, d))
+                    wg_att.append(ops.gemm_problem(doexp, Av, b["dWf"][i][d:], d, d, rows, ld, ld, d))
+                else:
+                    wg_att.append(ops.gemm_problem(dk, b["khat"], b["dWf"][i][:d], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][:d]))
+                    wg_att.append(ops.gemm_problem(dv, b["vhat"], b["dWf"][i][d:], d, d, Rk, ldk, ld, d, colsum_a=b["dbf"][i][d:]))
                 if c.biprojection:   # query was not normalised: its gradient joins the residual stream directly
                     dg_q.append(ops.gemm_problem(dq, st.sptr(ipw, 0), dx, Rq, d, d, ld, ld, d, flags=F_ACCUM))
                 else:
@@ -984,7 +1034,9 @@ class EncoderGroupPlan:
                       (ops.attn_bwd_dq, self.dtype, A(AttnProblem, att)),
                       # dK / dV feed only side work: beside the main chain where the side stream has slack (see _DKV_SIDE_ENV)
                       ((SIDE if self._dkv_side == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
-                       if self._dkv_side in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))] + \
+                       if self._dkv_side in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))][:3 if lr else 4] + \
+                     ([(SIDE, (ops.expand_heads, self.dtype, A(ExpandProblem, lr_exp))), (SIDE, self._gemm(GEMM_NN, lr_qk)),
+                       (SIDE, self._gemm(GEMM_NN, lr_u))] if lr else []) + \
                      ([] if x3 else [wg_att_step]) + [self._gemm(GEMM_NN, dg_q)] + ([wg_att_step] if x3 else [])
             if lnq:
                 steps.append((ops.ln_bwd, A(LnProblem, lnq), d))
@@ -1004,11 +1056,17 @@ class EncoderGroupPlan:
         # encoder; then -> d(embedded key / value source): LayerNorm backward without affine
         hat, dg_kv = [], []
         for e, b in zip(self.encs, self.buf):
-            dg_kv += [ops.gemm_problem(b["dkall"], st.sptr(e.prefix + KSTACK), b["Gk"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d),
-                      ops.gemm_problem(b["dvall"], st.sptr(e.prefix + VSTACK), b["Gv"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d)]
+            if self._lowrank:        # d(khat) of batch element bb = dS_all[:, bb]^T (Qexp W_k')_all[:, bb], K = layers H T
+                KK, Sp = c.layers * H * e.T, b["Sp"]
+                for bb in range(B):
+                    for mat, prod, G_ in ((b["dSall"], b["qkall"], b["Gk"]), (b["Pdall"], b["daall"], b["Gv"])):
+                        dg_kv.append(ops.gemm_problem(mat[0, 0, bb], prod.view(KK, B, ld)[0, bb], G_[bb], e.S, d, KK, B * Sp, B * ld, B * d))
+            else:
+                dg_kv += [ops.gemm_problem(b["dkall"], st.sptr(e.prefix + KSTACK), b["Gk"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d),
+                          ops.gemm_problem(b["dvall"], st.sptr(e.prefix + VSTACK), b["Gv"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d)]
             hat += [ops.ln_problem(b["ke"], self._ones, None, b["stk"][0], b["stk"][1], b["Rk"], dy=b["Gk"], ldy=d, dx=b["dke"]),
                     ops.ln_problem(b["ve"], self._ones, None, b["stv"][0], b["stv"][1], b["Rk"], dy=b["Gv"], ldy=d, dx=b["dve"])]
-        steps += [(SIDE, self._gemm(GEMM_NN, dg_kv)), (SIDE, (ops.ln_bwd, A(LnProblem, hat), d)), JOIN]
+        steps += [(SIDE, self._gemm(GEMM_TN if self._lowrank else GEMM_NN, dg_kv)), (SIDE, (ops.ln_bwd, A(LnProblem, hat), d)), JOIN]
         return steps
 
     @staticmethod

@@ -260,9 +260,14 @@ class _X3Plan:
 # attention
 # ----------------------------------------------------------------------------
 def attn_problem(Q, K, V, O, ldo, lse, B, H, T, S, dh, dhp, mask_off, *, dO=None, delta=None, dQ=None, lddq=0,
-                 dK=None, lddk=0, dV=None, lddv=0, dq_scale=1.0, drop_p=0.0, drop_site=0, q_pos0=0, q_stride=1) -> AttnProblem:
+                 dK=None, lddk=0, dV=None, lddv=0, dq_scale=1.0, drop_p=0.0, drop_site=0, q_pos0=0, q_stride=1,
+                 dS=None, Pd=None, xs=(0, 0, 0)) -> AttnProblem:
+    """dS / Pd (attn_bwd_dq only): CT tensors that receive the score gradient and the dropped probabilities, element
+    (b, h, i, j) at b*xs[0] + h*xs[1] + i*xs[2] + j."""
     p = AttnProblem()
     p.q_pos0, p.q_stride = q_pos0, q_stride
+    p.dS, p.Pd = _p(dS), _p(Pd)
+    p.xs_b, p.xs_h, p.xs_q = xs
     p.Q, p.K, p.V, p.O, p.ldo, p.lse = _p(Q), _p(K), _p(V), _p(O), ldo, _f32(lse, "lse")
     p.dO, p.delta = _p(dO), _f32(delta, "delta")
     p.dQ, p.lddq, p.dK, p.lddk, p.dV, p.lddv = _p(dQ), lddq, _p(dK), lddk, _p(dV), lddv
@@ -491,6 +496,21 @@ def addn_problem(out, ins) -> "_lib.AddnProblem":
     for j, t in enumerate(ins):
         p.src[j] = _p(t)
     return p
+
+
+def expand_problem(q, dO, qexp, dOexp, B, H, T, dh, dhp, ld, *, Pd=None, S=0, dbias=None) -> "_lib.ExpandProblem":
+    """bpm_expand_heads: head-major q / dO [B,H,T,dhp] -> block rows [(h*T+t)*B+b, ld]; dbias[H*dh] (written) =
+    sum_{b,t} rowsum(Pd row) * dO[b,h,t,:]."""
+    p = _lib.ExpandProblem()
+    p.q, p.dO, p.qexp, p.dOexp, p.Pd, p.dbias = _p(q), _p(dO), _p(qexp), _p(dOexp), _p(Pd), _f32(dbias, "expand.dbias")
+    p.B, p.H, p.T, p.S, p.dh, p.dhp, p.ld = B, H, T, S, dh, dhp, ld
+    return p
+
+
+def expand_heads(dtype: int, probs) -> None:
+    arr = _as_array(_lib.ExpandProblem, probs)
+    for sub, k in _chunks(arr, _lib.ExpandProblem, None):
+        _lib.check(_lib.lib().bpm_expand_heads(dtype, sub, k, _stream()), "bpm_expand_heads")
 
 
 def add_n(probs) -> None:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define BPM_ABI_VERSION 2
+#define BPM_ABI_VERSION 3
 #define BPM_SEED_INDIRECT (1ull << 63) /* seed = BPM_SEED_INDIRECT | (uintptr_t)device pointer to the uint64 seed */
 #define BPM_MAX_GROUP 18 /* problems per grouped launch (6 encoders of a level x 3 projections) */
 #define BPM_GEMM_MAX_GROUP 24 /* bpm_gemm_grouped alone: 6 encoders x (q, k, v, out) weight gradients in one launch */
@@ -76,8 +76,10 @@ enum { BPM_OUT_F32 = 0, BPM_OUT_CT = 1, BPM_OUT_HEADS = 2 };
  * itself and no window matrix is materialised (frontend.py; reference mmtr.py:93-108).  Needs BPM_GEMM_KPAD_ZERO
  * (hardware-bounded loads only: the operand must be readable up to (rows-1)*ld + length), and K % 64 == 0 when the
  * overlapping operand is k-contiguous (its k tail would otherwise read the next window's data instead of zeros). */
+/* BPM_GEMM_CT_NARROW: a BPM_OUT_CT output writes its N columns only (by default the pad columns [N, ldc) of every row
+ * receive zeros): for outputs whose rows are interleaved with other tensors' rows (ldc = several logical rows). */
 enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4, BPM_GEMM_KPAD_ZERO = 8, BPM_GEMM_BACKGROUND = 16,
-       BPM_GEMM_A_OVERLAP = 32, BPM_GEMM_B_OVERLAP = 64 };
+       BPM_GEMM_A_OVERLAP = 32, BPM_GEMM_B_OVERLAP = 64, BPM_GEMM_CT_NARROW = 128 };
 
 typedef struct bpm_gemm_problem {
     const void* A;          /* CT */
@@ -136,6 +138,12 @@ typedef struct bpm_attn_problem {
     uint32_t drop_site;
     int q_pos0, q_stride;   /* query row i is time step q_pos0 + i*q_stride for the mask rule (stride 0 = 1): a
                                gathered subset of query rows keeps its original visibility */
+    /* bpm_attn_bwd_dq only, optional (both or neither; S % 4 == 0): dS = P o (drop o dP - delta), the gradient of the
+     * scores, and Pd = drop o P, the probabilities after dropout, as CT elements at b*xs_b + h*xs_h + i*xs_q + j.  With a
+     * handful of query rows dK = dS^T Q and dV = Pd^T dO have rank T per head and the caller may continue from these
+     * [rows, S] matrices instead of bpm_attn_bwd_dkv (multihead_attention.py:110-130 backward). */
+    void* dS; void* Pd;
+    int xs_b, xs_h, xs_q;
 } bpm_attn_problem;
 
 int bpm_attn_fwd(int dtype, const bpm_attn_problem* probs /* host */, int nprob, uint64_t seed, void* stream);
@@ -308,6 +316,20 @@ typedef struct bpm_addn_problem {
     size_t count;
 } bpm_addn_problem;
 int bpm_add_n(const bpm_addn_problem* probs, int n, void* stream);
+
+/* Head-major q / dO [B,H,T,dhp] (the attention operands) -> block rows [(h*T + t)*B + b, ld]: columns [h*dh, (h+1)*dh)
+ * hold the head's vector, every other column zero -- the per-head products of the engine's low-rank key side (groups
+ * with a handful of query rows) then are plain grouped GEMMs over all heads.  dbias (optional, [H*dh], WRITTEN):
+ * sum_{b,t} rowsum(Pd[(h*T+t)*B+b, 0:S]) * dO[b,h,t,:], the value-projection bias gradient (column sums of
+ * dV = Pd^T dO; multihead_attention.py:100-104 backward). */
+typedef struct bpm_expand_problem {
+    const void* q; const void* dO;      /* CT [B,H,T,dhp] */
+    void* qexp; void* dOexp;            /* CT [H*T*B, ld] */
+    const void* Pd;                     /* CT [H*T*B, S] (bpm_attn_problem.Pd with xs_h = T*B*S, xs_q = B*S, xs_b = S) or NULL */
+    float* dbias;                       /* or NULL */
+    int B, H, T, S, dh, dhp, ld;
+} bpm_expand_problem;
+int bpm_expand_heads(int dtype, const bpm_expand_problem* probs /* host */, int n, void* stream);
 
 int bpm_gmu2_fwd(const bpm_gmu_problem* probs, int n, int d, void* stream);
 int bpm_gmu2_bwd(int dtype, const bpm_gmu_problem* probs, int n, int d, void* stream);

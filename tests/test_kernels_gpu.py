@@ -384,6 +384,77 @@ def test_attention_fwd_bwd(dtype, B, H, T, S, dh, masked, pdrop):
 
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,T,S,dh,pdrop,qpos", [(2, 3, 2, 200, 25, 0.0, (0, 199)), (3, 2, 2, 72, 64, 0.2, (0, 71)),
+                                                    (2, 2, 4, 132, 128, 0.1, (0, 1)), (1, 2, 2, 512, 64, 0.1, (0, 511))])
+def test_attention_dq_pass_exports_score_gradient_and_dropped_probabilities(dtype, B, H, T, S, dh, pdrop, qpos):
+    """bpm_attn_bwd_dq with dS / Pd: the [rows, S] factors of dK = dS^T Q and dV = Pd^T dO (the engine's low-rank key side),
+    in the [h*T + t][b][padded keys] layout the engine uses, against fp64 torch with the library's dropout masks; then
+    bpm_expand_heads on the same operands against torch."""
+    dhp = 32 if dh <= 32 else (64 if dh <= 64 else 128)
+    ctt = ops.ct_torch(dtype)
+    d, ld, Sp = H * dh, pad32(H * dh), (S + 63) // 64 * 64
+
+    def heads(x):
+        buf = torch.zeros(*x.shape[:3], dhp, dtype=ctt)
+        buf[..., :dh] = x.to(ctt)
+        return buf.to(DEV), buf[..., :dh].double()
+
+    Q, q = heads(rnd(B, H, T, dh, seed=31) * dh ** -0.5)
+    K, k = heads(rnd(B, H, S, dh, seed=32))
+    V, v = heads(rnd(B, H, S, dh, seed=33))
+    dO, do = heads(rnd(B, H, T, dh, seed=34))
+    pos0, stride = qpos[0], (qpos[1] - qpos[0]) if T == 2 else 1
+    off = 1                                              # T_full = S: key j visible to the query at time step i iff j <= i
+    pm = drop_mult((B, H, T, S), pdrop, 9, 3).double()
+    sc = q @ k.transpose(-1, -2)
+    tpos = pos0 + stride * torch.arange(T)
+    sc = sc.masked_fill((torch.arange(S)[None, :] - tpos[:, None]) >= off, float("-inf"))
+    pr = torch.softmax(sc, -1)
+    pd_ref = pr * pm
+    o = pd_ref @ v
+    dp = do @ v.transpose(-1, -2)
+    ds_ref = pr * (pm * dp - (do * o).sum(-1, keepdim=True))
+
+    O = torch.zeros(T * B, ld, device=DEV, dtype=ctt)
+    lse, delta = torch.zeros(B, H, T, device=DEV), torch.zeros(B, H, T, device=DEV)
+    dQ = torch.zeros(T * B, ld, device=DEV, dtype=ctt)
+    dS = torch.full((H * T, B, Sp), 7.0, device=DEV, dtype=ctt)
+    Pd = torch.full((H * T, B, Sp), 7.0, device=DEV, dtype=ctt)
+    p = ops.attn_problem(Q, K, V, O, ld, lse, B, H, T, S, dh, dhp, off, dO=dO, delta=delta, dQ=dQ, lddq=ld, dq_scale=1.0,
+                         drop_p=pdrop, drop_site=3, q_pos0=pos0, q_stride=stride, dS=dS, Pd=Pd, xs=(Sp, T * B * Sp, B * Sp))
+    ops.attn_fwd(dtype, [p], seed=9)
+    ops.attn_bwd_dq(dtype, [p], seed=9)
+    torch.cuda.synchronize()
+    t = 1e-4 if dtype == BPM_F32 else 3e-2
+    got_ds = dS.float().reshape(H, T, B, Sp).permute(2, 0, 1, 3)
+    got_pd = Pd.float().reshape(H, T, B, Sp).permute(2, 0, 1, 3)
+    # keys beyond the last visible one of the block's last query are never visited: they keep what the buffer held
+    vis = int(min(S, tpos.max().item() + off))
+    nt = (vis + 63) // 64 * 64
+    close(got_ds[..., :min(nt, S)], ds_ref[..., :min(nt, S)], t, "dS")
+    close(got_pd[..., :min(nt, S)], pd_ref[..., :min(nt, S)], t, "Pd")
+    assert (got_ds[..., S:] == 7.0).all() and (got_pd[..., S:] == 7.0).all(), "key padding must not be written"
+    # ---- expand_heads
+    qexp = torch.full((H * T * B, ld), 5.0, device=DEV, dtype=ctt)
+    doexp = torch.full((H * T * B, ld), 5.0, device=DEV, dtype=ctt)
+    dbias = torch.full((d,), 3.0, device=DEV)
+    Pz = Pd.clone()
+    Pz[..., S:] = 0                                      # the engine's buffers are zero there
+    ops.expand_heads(dtype, [ops.expand_problem(Q, dO, qexp, doexp, B, H, T, dh, dhp, ld, Pd=Pz, S=Sp, dbias=dbias)])
+    torch.cuda.synchronize()
+    ref_q = torch.zeros(H, T, B, ld, dtype=torch.float64)
+    ref_do = torch.zeros(H, T, B, ld, dtype=torch.float64)
+    for h in range(H):
+        ref_q[h, :, :, h * dh:(h + 1) * dh] = q[:, h].permute(1, 0, 2)
+        ref_do[h, :, :, h * dh:(h + 1) * dh] = do[:, h].permute(1, 0, 2)
+    assert torch.equal(qexp.float().cpu().double().reshape(H, T, B, ld), ref_q)
+    assert torch.equal(doexp.float().cpu().double().reshape(H, T, B, ld), ref_do)
+    rs = Pz.float().cpu().double().reshape(H, T, B, Sp).sum(-1)                    # [H, T, B]
+    ref_b = torch.einsum("htb,bhtj->hj", rs, do).reshape(d)
+    close(dbias, ref_b, 1e-5 if dtype == BPM_F32 else 1e-3, "value-bias gradient")
+
+
 @pytest.mark.parametrize("T,S,dh", [(320, 320, 64), (65, 200, 25), (513, 512, 64), (64, 64, 128)])
 def test_attention_block_pairing_is_bitwise_neutral(T, S, dh):
     """A workgroup of the attention kernels takes two 64-row blocks (b, nblk-1-b); the tuning hook switches every kernel

@@ -66,8 +66,17 @@ def test_launch_tables_build_from_host_tensors(dry_run, model, kw, prune):
             per = 6 if plan.cfg.biprojection else 4
             assert n_first == per * L * len(plan.encs), (n_first, per, L)
         # every layer's dK / dV block sits inside the stacked buffer the merged data-gradient product reads
-        for b in plan.buf:
-            assert b["dkall"].shape == (b["Rk"], L * plan.ld) and b["Gk"].shape == (b["Rk"], plan.cfg.d)
+        # (low-rank key side -- a handful of query time steps, level 2 under dead-row elimination: dS / Pd of every layer
+        # instead, [layer][h*T + t][b][padded keys], and the merged product runs over K = layers * H * T)
+        assert plan._lowrank == (prune and model == "mmtrvat" and plan is trunk.plan2)
+        for e, b in zip(plan.encs, plan.buf):
+            assert b["Gk"].shape == (b["Rk"], plan.cfg.d)
+            if plan._lowrank:
+                HT = plan.cfg.H * e.T
+                assert b["dkall"] is None and b["dSall"].shape == b["Pdall"].shape == (L, HT, 2, b["Sp"]) and b["Sp"] % 64 == 0
+                assert b["qkall"].shape == b["daall"].shape == (L, HT * 2, plan.ld)
+            else:
+                assert b["dkall"].shape == (b["Rk"], L * plan.ld)
     # the zero list covers everything but the large encoder matrices, without overlapping them
     tab, nd, nblk = st._zero_table
     assert nd > 0 and nblk >= nd
