@@ -32,7 +32,7 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_F32, OUT_CT, OUT_HEADS = 0, 1, 2
 F_ACCUM, F_RELU, F_ATOMIC, F_KPAD, F_BACKGROUND = 1, 2, 4, 8, 16     # F_KPAD = BPM_GEMM_KPAD_ZERO
 F_A_OVERLAP, F_B_OVERLAP = 32, 64                                     # BPM_GEMM_A_OVERLAP / _B_OVERLAP
-F_CT_NARROW = 128                                                     # BPM_GEMM_CT_NARROW
+F_CT_NARROW, F_BATCHED = 128, 256                                     # BPM_GEMM_CT_NARROW / _BATCHED
 LN_OUT_F32 = 2
 MAX_GROUP = 18
 SEED_INDIRECT = 1 << 63          # seed = SEED_INDIRECT | device address of a uint64 (include/bpmult_hip.h)
@@ -111,7 +111,8 @@ class GemmProblem(C.Structure):
                 ("colsum", C.c_void_p),
                 ("flags", C.c_int), ("out_kind", C.c_int), ("splitk", C.c_int),
                 ("heads_B", C.c_int), ("heads_H", C.c_int), ("heads_T", C.c_int),
-                ("heads_dh", C.c_int), ("heads_dhp", C.c_int), ("colsum_a", C.c_void_p)]
+                ("heads_dh", C.c_int), ("heads_dhp", C.c_int), ("colsum_a", C.c_void_p),
+                ("batch", C.c_int), ("batch_stride_a", C.c_int), ("batch_stride_b", C.c_int), ("batch_stride_c", C.c_int)]
 
 
 class AttnProblem(C.Structure):

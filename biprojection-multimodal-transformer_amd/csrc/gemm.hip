@@ -227,7 +227,7 @@ BPM_DEV void flush_colsum(const Prob& P, float (&csum)[4], int nb, int r) {
 BPM_DEV bool epi_fast_ok(const Prob& P) {
     const uintptr_t al = (uintptr_t)P.bias_n | (uintptr_t)P.resid | (uintptr_t)P.C | (uintptr_t)P.gate;
     return (P.N & 3) == 0 && (al & 15) == 0 && ((P.ldr | P.ldc | P.ldg) & 3) == 0 && !P.bias_m &&
-           !(P.flags & BPM_GEMM_ATOMIC) && P.splitk == 1 && !(P.resid && (P.flags & BPM_GEMM_ACCUM));
+           !(P.flags & BPM_GEMM_ATOMIC) && (P.splitk == 1 || (P.flags & BPM_GEMM_BATCHED)) && !(P.resid && (P.flags & BPM_GEMM_ACCUM));
 }
 
 struct EpiRow {            // per output row m: everything that does not depend on the column
@@ -291,12 +291,14 @@ BPM_DEV void epi_fast_load(const Prob& P, int mrow, int nb, EpiSide<CT, NB>& s) 
 }
 
 template <typename CT, int NB>
-BPM_DEV void epi_fast_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NB], const EpiSide<CT, NB>& s, f32x4& csum) {
+BPM_DEV void epi_fast_apply(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NB], const EpiSide<CT, NB>& s, f32x4& csum,
+                            uint32_t coff = 0) {     // coff: element offset of this batch element's output (BPM_GEMM_BATCHED)
     const bool colok = nb < P.N;                        // N % 4 == 0: a lane's 4 columns are all in or all out
     const bool f32out = P.out_kind == BPM_OUT_F32;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const EpiRow e = epi_row(P, mrow + 16 * b);
+        EpiRow e = epi_row(P, mrow + 16 * b);
+        e.offc += coff;
         const bool valid = e.ok && colok;
         f32x4 x = acc[b];
         if (valid) {
@@ -345,18 +347,19 @@ BPM_DEV void epi_fast_apply(const Prob& P, const DropCfg& drop, int mrow, int nb
 }
 
 template <typename CT, int NB>
-BPM_DEV void epilogue_fast(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NB], f32x4& csum) {
+BPM_DEV void epilogue_fast(const Prob& P, const DropCfg& drop, int mrow, int nb, const f32x4 (&acc)[NB], f32x4& csum, uint32_t coff = 0) {
     EpiSide<CT, NB> s;
     epi_fast_load<CT, NB>(P, mrow, nb, s);
-    epi_fast_apply<CT, NB>(P, drop, mrow, nb, acc, s, csum);
+    epi_fast_apply<CT, NB>(P, drop, mrow, nb, acc, s, csum, coff);
 }
 
 // one wave's column block: rows (m0 + 16*b + r), b < NB, columns nb..nb+3
 template <typename CT, int NB>
-BPM_DEV void epilogue_cols(const Prob& P, const DropCfg& drop, bool fast, bool lead, int m0, int r, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB]) {
+BPM_DEV void epilogue_cols(const Prob& P, const DropCfg& drop, bool fast, bool lead, int m0, int r, int nb, const f32x4 (&acc)[NB], const EpiRow (&rows)[NB],
+                           uint32_t coff = 0) {
     if (fast) {
         f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
-        epilogue_fast<CT, NB>(P, drop, m0 + r, nb, acc, cs);
+        epilogue_fast<CT, NB>(P, drop, m0 + r, nb, acc, cs, coff);
         if (P.colsum) { float c4[4] = {cs[0], cs[1], cs[2], cs[3]}; flush_colsum(P, c4, nb, r); }
     } else {
         float csum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -526,14 +529,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
     const Prob& P = pick_problem(grp, bid);
     if (BPM_BASE_PRIO && XK && !(P.flags & BPM_GEMM_BACKGROUND)) __builtin_amdgcn_s_setprio(BPM_BASE_PRIO);   // critical path
     const int tiles = P.tiles_m * P.tiles_n;
-    const int split = bid / tiles;
+    const int split = bid / tiles;                      // split-K slice -- or the batch element of a BPM_GEMM_BATCHED problem
     const int t = bid % tiles;
     const int m0 = (t / P.tiles_n) * BMT, n0 = (t % P.tiles_n) * BN;
+    const bool batched = (P.flags & BPM_GEMM_BATCHED) != 0;      // uniform; element strides travel in hB / hH / hT
 
     constexpr int BK = SX::BK;
     const int nkt_all = (P.K + BK - 1) / BK;
-    const int per = (nkt_all + P.splitk - 1) / P.splitk;
-    const int kt_lo = split * per;
+    const int per = batched ? nkt_all : (nkt_all + P.splitk - 1) / P.splitk;
+    const int kt_lo = batched ? 0 : split * per;
     const int kt_hi = min(nkt_all, kt_lo + per);
 
     f32x4 acc[TN][TMT];
@@ -581,8 +585,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
         }
     };
 
-    const char* const Xp = P.X;
-    const char* const Yp = P.Y;
+    const char* const Xp = P.X + (batched ? (size_t)split * (size_t)P.hB * sizeof(CT) : (size_t)0);
+    const char* const Yp = P.Y + (batched ? (size_t)split * (size_t)P.hH * sizeof(CT) : (size_t)0);
     const int ldx = P.ldx, ldy = P.ldy, Mb = P.M, Nb = P.N, Kb = P.K;
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rsx, rsy;
     [[maybe_unused]] int vx[SX::PER_THREAD], vy[SY::PER_THREAD];
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
     }
 
     const int r = lane & 15, g = lane >> 4;
-    const bool lead = (split == 0);
+    const bool lead = batched || (split == 0);
     if constexpr (!XK && !YK) {
         if (do_xs && g == 0) {               // every row of the ones-product holds the sums: lane r has column m
 #pragma unroll
@@ -690,12 +694,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu((!XK &
     EpiRow rows[TMT];
 #pragma unroll
     for (int b = 0; b < TMT; ++b) rows[b] = epi_row(P, mw + 16 * b + r);
+    const uint32_t coff = batched ? (uint32_t)split * (uint32_t)P.hT : 0u;    // (host: 4-wide epilogue only, no side operands)
     BPM_TRACE(12);
     // (explicitly unrolled: a rolled loop would index the accumulators dynamically and send them to scratch)
     auto epi = [&](auto A) {           // colsum shuffles: uniform per workgroup, every lane takes part
         constexpr int a = decltype(A)::value;
         if constexpr (a < TN) {
-            epilogue_cols<CT, TMT>(P, drop, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows);
+            epilogue_cols<CT, TMT>(P, drop, fast, lead, mw, r, n0 + wn * (BN / WN) + 16 * a + 4 * g, acc[a], rows, coff);
             BPM_TRACE(13 + a);
         }
     };
@@ -979,7 +984,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         for (int i = 0; i < nprob && legal; ++i) {
             const bpm_gemm_problem& q = probs[i];
             const long kceil = ((long)q.K + DK - 1) / DK * DK;
-            legal = q.splitk <= 1 && !(q.flags & BPM_GEMM_ATOMIC) && (!xk || (q.flags & BPM_GEMM_A_OVERLAP) || kceil <= q.lda) &&
+            legal = q.splitk <= 1 && !(q.flags & (BPM_GEMM_ATOMIC | BPM_GEMM_BATCHED)) && (!xk || (q.flags & BPM_GEMM_A_OVERLAP) || kceil <= q.lda) &&
                     (!yk || (q.flags & BPM_GEMM_B_OVERLAP) || kceil <= q.ldb);
             if (x3) {       // a plane (half the leading dimension) holds whole k stages / whole 128-column sub-images, no overlap
                 const long pa = q.lda / 2, pb = q.ldb / 2, m128 = ((long)q.M + 127) / 128 * 128, n128 = ((long)q.N + 127) / 128 * 128;
@@ -1052,7 +1057,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     bool skinny = dma < 0 && !x3 && variant != BPM_GEMM_TN && fast;
     for (int i = 0; i < nprob && skinny; ++i) {
         const bpm_gemm_problem& q = probs[i];
-        skinny = q.M <= 16 && q.splitk <= 1 && !(q.flags & (BPM_GEMM_ATOMIC | BPM_GEMM_A_OVERLAP | BPM_GEMM_B_OVERLAP)) &&
+        skinny = q.M <= 16 && q.splitk <= 1 && !(q.flags & (BPM_GEMM_ATOMIC | BPM_GEMM_A_OVERLAP | BPM_GEMM_B_OVERLAP | BPM_GEMM_BATCHED)) &&
                  ((long)q.lda * sz) % 64 == 0 && (variant != BPM_GEMM_NT || ((long)q.ldb * sz) % 64 == 0);
     }
     // under-filled weight-gradient launches (fewer than two 128-row workgroups per CU) run 64-row workgroups:
@@ -1098,6 +1103,19 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         p.tiles_n = ntiles;
         p.splitk = q.splitk > 1 ? q.splitk : 1;
         if (p.splitk > 1 && !((q.flags & BPM_GEMM_ATOMIC) && q.out_kind == BPM_OUT_F32)) return BPM_ERR_ARG;
+        if (q.flags & BPM_GEMM_BATCHED) {
+            // `batch` independent products of one shape: operand / output i starts batch_stride_* elements behind i - 1.  The
+            // 128 x 64 kernel only; the batch index travels where the split-K slice does, the strides in the head fields
+            // (plain stores through the 4-wide epilogue, no side operands).
+            const uintptr_t al = (uintptr_t)q.C | (uintptr_t)q.bias_n;
+            if (x3 || dma >= 0 || skinny || q.batch < 1 || q.batch > 4096 || q.splitk > 1 || q.out_kind == BPM_OUT_HEADS || q.bias_m || q.resid ||
+                q.gate || q.colsum || q.colsum_a || q.drop_p != 0.f || (q.flags & (BPM_GEMM_ATOMIC | BPM_GEMM_ACCUM)) ||
+                (q.N & 3) || (q.ldc & 3) || (al & 15) || q.batch_stride_a < 0 || q.batch_stride_b < 0 || q.batch_stride_c < 0 ||
+                ((q.batch_stride_a * sz) & 15) || ((q.batch_stride_b * sz) & 15) || (q.batch_stride_c & 3))
+                return BPM_ERR_ARG;
+            p.splitk = q.batch;
+            p.hB = q.batch_stride_a; p.hH = q.batch_stride_b; p.hT = q.batch_stride_c;
+        }
         tile += p.tiles_m * p.tiles_n * p.splitk;
     }
     g.total_tiles = tile;
@@ -1105,7 +1123,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
     double flops = 0, bytes = 0;
     for (int i = 0; i < nprob; ++i) {
         const bpm_gemm_problem& q = probs[i];
-        flops += 2.0 * q.M * (double)q.N * q.K;
+        flops += 2.0 * q.M * (double)q.N * q.K * ((q.flags & BPM_GEMM_BATCHED) ? q.batch : 1);
         // algorithmic HBM bytes: each operand once, the output once, each side operand of the epilogue once
         const double mn = (double)q.M * q.N;
         bytes += ((double)q.M + q.N) * q.K * sz + mn * (q.out_kind == BPM_OUT_F32 ? 4 : sz);

@@ -876,7 +876,7 @@ class EncoderGroupPlan:
             s_cast0, s_dgout0, s_att0, s_wg0, s_dg0a, s_dg0b, s_dg0c, s_ln0 = [], [], [], [], [], [], [], []
             s_dgq, s_scatter = [], []                 # tail_rows (last layer): d(LN0 rows {0, T-1}) and the scatter back to [R, d]
             lr = self._lowrank
-            lr_exp, lr_qk, lr_u = [], [], []          # low-rank key side: head expansion, Qexp W' products, dS khat / Pd vhat
+            lr_exp, lr_qk = [], []                    # low-rank key side: head expansion; Qexp W' and dS khat / Pd vhat products
             pre_ffn, pre_att = [], []                 # bf16x3: operands of the weight gradients whose split image already exists
             for e, b in zip(self.encs, self.buf):
                 R, Rk = b["R"], b["Rk"]
@@ -951,10 +951,10 @@ class EncoderGroupPlan:
                     for src, stack, dst in ((qexp, KSTACK, b["qkall"][i]), (doexp, VSTACK, b["daall"][i])):
                         lr_qk.append(ops.gemm_problem(src, st.sptr(e.prefix + stack, i * ld * ld), dst, rows, d, d, ld, ld, ld,
                                                       out_kind=OUT_CT))
-                    for bb in range(B):                  # per batch element: [H T, S] x [S, d] (rows of batch element bb: stride B)
-                        for mat, hat_, dst in ((b["dSall"][i], b["khat"], U), (b["Pdall"][i], b["vhat"], Av)):
-                            lr_u.append(ops.gemm_problem(mat[0, bb], hat_[bb], dst[bb], HT, d, e.S, B * Sp, B * ld, B * ld,
-                                                         out_kind=OUT_CT, flags=F_CT_NARROW))
+                    # per batch element: [H T, S] x [S, d]; the rows of a batch element are B rows apart in all three tensors
+                    for mat, hat_, dst in ((b["dSall"][i], b["khat"], U), (b["Pdall"][i], b["vhat"], Av)):
+                        lr_qk.append(ops.gemm_problem(mat, hat_, dst, HT, d, e.S, B * Sp, B * ld, B * ld, out_kind=OUT_CT,
+                                                      flags=F_CT_NARROW, batch=(B, Sp, ld, ld)))
                     wg_att.append(ops.gemm_problem(qexp, U, b["dWf"][i][:d], d, d, rows, ld, ld, d))
                     wg_att.append(ops.gemm_problem(doexp, Av, b["dWf"][i][d:], d, d, rows, ld, ld, d))
                 else:
@@ -1035,11 +1035,14 @@ class EncoderGroupPlan:
                       # dK / dV feed only side work: beside the main chain where the side stream has slack (see _DKV_SIDE_ENV)
                       ((SIDE if self._dkv_side == "1" else SIDE2, (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))
                        if self._dkv_side in ("1", "2") else (ops.attn_bwd_dkv, self.dtype, A(AttnProblem, att)))][:3 if lr else 4] + \
-                     ([(SIDE, (ops.expand_heads, self.dtype, A(ExpandProblem, lr_exp))), (SIDE, self._gemm(GEMM_NN, lr_qk)),
-                       (SIDE, self._gemm(GEMM_NN, lr_u))] if lr else []) + \
-                     ([] if x3 else [wg_att_step]) + [self._gemm(GEMM_NN, dg_q)] + ([wg_att_step] if x3 else [])
+                     ([] if x3 or lr else [wg_att_step]) + [self._gemm(GEMM_NN, dg_q)] + ([wg_att_step] if x3 and not lr else [])
             if lnq:
                 steps.append((ops.ln_bwd, A(LnProblem, lnq), d))
+            if lr:
+                # low-rank key side: no dK / dV pass; the side stream continues from the dS / Pd the dQ pass wrote.  Issued
+                # BEHIND the rest of the layer's main chain
+                steps += [(SIDE, (ops.expand_heads, self.dtype, A(ExpandProblem, lr_exp))), (SIDE, self._gemm(GEMM_NN, lr_qk)),
+                          wg_att_step]
             if c.biprojection:
                 steps += [(ops.rows_cast, self.dtype, A(CastProblem, s_cast0)),
                           self._gemm(GEMM_NN, s_dgout0),
@@ -1058,9 +1061,8 @@ class EncoderGroupPlan:
         for e, b in zip(self.encs, self.buf):
             if self._lowrank:        # d(khat) of batch element bb = dS_all[:, bb]^T (Qexp W_k')_all[:, bb], K = layers H T
                 KK, Sp = c.layers * H * e.T, b["Sp"]
-                for bb in range(B):
-                    for mat, prod, G_ in ((b["dSall"], b["qkall"], b["Gk"]), (b["Pdall"], b["daall"], b["Gv"])):
-                        dg_kv.append(ops.gemm_problem(mat[0, 0, bb], prod.view(KK, B, ld)[0, bb], G_[bb], e.S, d, KK, B * Sp, B * ld, B * d))
+                for mat, prod, G_ in ((b["dSall"], b["qkall"], b["Gk"]), (b["Pdall"], b["daall"], b["Gv"])):
+                    dg_kv.append(ops.gemm_problem(mat, prod, G_, e.S, d, KK, B * Sp, B * ld, B * d, batch=(B, Sp, ld, d)))
             else:
                 dg_kv += [ops.gemm_problem(b["dkall"], st.sptr(e.prefix + KSTACK), b["Gk"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d),
                           ops.gemm_problem(b["dvall"], st.sptr(e.prefix + VSTACK), b["Gv"], b["Rk"], d, c.layers * ld, c.layers * ld, ld, d)]

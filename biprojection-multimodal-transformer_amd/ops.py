@@ -89,8 +89,10 @@ def _as_array(cls, probs):
 def gemm_problem(A, B, Cc, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, bias_n=None, bias_m=None,
                  resid=None, ldr: int = 0, gate=None, ldg: int = 0, gate_scale: float = 1.0, alpha: float = 1.0,
                  drop_p: float = 0.0, drop_site: int = 0, colsum=None, flags: int = 0, out_kind: int = OUT_F32,
-                 splitk: int = 1, heads=None, colsum_a=None) -> GemmProblem:
-    """A, B, C: tensors or raw device addresses (int).  heads = (B, H, T, dh, dhp) for OUT_HEADS."""
+                 splitk: int = 1, heads=None, colsum_a=None, batch=None) -> GemmProblem:
+    """A, B, C: tensors or raw device addresses (int).  heads = (B, H, T, dh, dhp) for OUT_HEADS.
+    batch = (n, stride_a, stride_b, stride_c): n products of this shape, operands / output of element i start i * stride
+    elements further on (BPM_GEMM_BATCHED)."""
     p = GemmProblem()
     p.A, p.B, p.C = (x if isinstance(x, int) else _p(x) for x in (A, B, Cc))
     p.M, p.N, p.K = M, N, K
@@ -104,6 +106,9 @@ def gemm_problem(A, B, Cc, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
     if heads is not None:
         p.heads_B, p.heads_H, p.heads_T, p.heads_dh, p.heads_dhp = heads
     p.colsum_a = colsum_a if isinstance(colsum_a, int) else _f32(colsum_a, "colsum_a")
+    if batch is not None:
+        p.batch, p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch
+        p.flags |= _lib.F_BATCHED
     return p
 
 

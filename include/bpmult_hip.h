@@ -79,7 +79,7 @@ enum { BPM_OUT_F32 = 0, BPM_OUT_CT = 1, BPM_OUT_HEADS = 2 };
 /* BPM_GEMM_CT_NARROW: a BPM_OUT_CT output writes its N columns only (by default the pad columns [N, ldc) of every row
  * receive zeros): for outputs whose rows are interleaved with other tensors' rows (ldc = several logical rows). */
 enum { BPM_GEMM_ACCUM = 1, BPM_GEMM_RELU = 2, BPM_GEMM_ATOMIC = 4, BPM_GEMM_KPAD_ZERO = 8, BPM_GEMM_BACKGROUND = 16,
-       BPM_GEMM_A_OVERLAP = 32, BPM_GEMM_B_OVERLAP = 64, BPM_GEMM_CT_NARROW = 128 };
+       BPM_GEMM_A_OVERLAP = 32, BPM_GEMM_B_OVERLAP = 64, BPM_GEMM_CT_NARROW = 128, BPM_GEMM_BATCHED = 256 };
 
 typedef struct bpm_gemm_problem {
     const void* A;          /* CT */
@@ -107,6 +107,10 @@ typedef struct bpm_gemm_problem {
      * dW = dY^T X: A = dY), taken from the operand tiles already in registers by one extra MFMA against a vector
      * of ones in the workgroups of the first N tile.  Needs splitk == 1.  NULL = off. */
     float* colsum_a;
+    /* BPM_GEMM_BATCHED: `batch` products of this shape in one problem; operands / output of element i start
+     * i * batch_stride_{a,b,c} elements behind the pointers above.  Plain stores (BPM_OUT_F32 / BPM_OUT_CT), no side
+     * operands, N % 4 == 0; the 128 x 64 kernel only. */
+    int batch, batch_stride_a, batch_stride_b, batch_stride_c;
 } bpm_gemm_problem;
 
 int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* probs /* host */, int nprob,

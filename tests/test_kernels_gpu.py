@@ -282,6 +282,46 @@ def test_gemm_nn_tn_and_splitk(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_gemm_batched_problems_with_interleaved_rows(dtype):
+    """BPM_GEMM_BATCHED + BPM_GEMM_CT_NARROW: the products of the engine's low-rank key side -- per batch element
+    [H T, S] x [S, d] with the rows of a batch element B rows apart in both operands and the output (NN, CT output that must
+    not touch its neighbours' rows), and the transposed product back (TN, fp32) -- beside a plain problem in the same launch."""
+    from bpmult_amd._lib import F_CT_NARROW
+    F_KPAD = ops.F_KPAD
+    B_, HT, S, d = 3, 10, 72, 96
+    Sp, ld = 128, pad32(d)
+    ctt = ops.ct_torch(dtype)
+    dS = torch.zeros(HT, B_, Sp, dtype=ctt)
+    dS[..., :S] = rnd(HT, B_, S, seed=41).to(ctt)
+    khat = torch.zeros(S, B_, ld, dtype=ctt)
+    khat[..., :d] = rnd(S, B_, d, seed=42, scale=S ** -0.5).to(ctt)
+    U = torch.full((HT, B_, ld), 9.0, dtype=ctt).to(DEV)
+    dSd, khd = dS.to(DEV), khat.to(DEV)
+    A2, A2r = to_ct(rnd(40, 64, seed=43), dtype)
+    W2, W2r = to_ct(rnd(64, 52, seed=44), dtype)
+    o2 = torch.zeros(40, 52, device=DEV)
+    ops.gemm_grouped(dtype, GEMM_NN, [
+        ops.gemm_problem(dSd, khd, U, HT, d, S, B_ * Sp, B_ * ld, B_ * ld, out_kind=OUT_CT, flags=F_CT_NARROW | F_KPAD,
+                         batch=(B_, Sp, ld, ld)),
+        ops.gemm_problem(A2, W2, o2, 40, 52, 64, A2.shape[1], W2.shape[1], 52)])
+    torch.cuda.synchronize()
+    ref = torch.einsum("kbs,sbn->kbn", dS[..., :S].double(), khat[..., :d].double())
+    t = tol(dtype) if dtype == BPM_F32 else 1e-2
+    close(U[..., :d].float(), ref, t, "batched NN")
+    assert (U[..., d:].float() == 9.0).all(), "CT_NARROW: pad columns stay untouched"
+    close(o2, A2r.double() @ W2r.double(), t, "plain problem beside it")
+    # back: G[(s, b), :] = sum_k dS[k, b, s] * U[k, b, :]
+    G = torch.full((S, B_, d), float("nan"), device=DEV)
+    Uc = U.clone()
+    Uc[..., d:] = 0
+    ops.gemm_grouped(dtype, GEMM_TN, [ops.gemm_problem(dSd, Uc, G, S, d, HT, B_ * Sp, B_ * ld, B_ * d, flags=F_KPAD,
+                                                       batch=(B_, Sp, ld, d))])
+    torch.cuda.synchronize()
+    refG = torch.einsum("kbs,kbn->sbn", dS[..., :S].double(), Uc[..., :d].float().cpu().double())
+    close(G, refG, t, "batched TN")
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_gemm_epilogues_grouped(dtype):
     """relu+dropout -> CT (fc1), gate (fc2 dgrad), heads scatter (Q proj), three problems in one launch."""
     M, N, K = 70, 100, 64
