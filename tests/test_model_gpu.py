@@ -440,7 +440,7 @@ def test_eval_mode_no_grad_and_state_dict_round_trip():
     m.eval()
     with torch.no_grad():
         out = m(x[0], None, None, x[1], x[2])
-    assert float((out - ref).abs().max()) <= 1e-5
+    assert float((out - ref).detach().abs().max()) <= 1e-5
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     m2 = _toy(seed=99)
     m2.load_state_dict(sd)
@@ -700,7 +700,7 @@ def test_text_encoder_from_local_directory_through_the_hip_trunk(tmp_path):
     assert float((logits - ref).detach().abs().max()) <= 1e-5
     # the reference's batch tuple (helpers.py:129-133) through training.model_forward (train.py:283-338)
     loss, out, _ = TR.model_forward(m_tok, torch.nn.BCEWithLogitsLoss(), (txt, seg, mask, img, tgt, aud), "mmtrvat")
-    assert float((out - ref).abs().max()) <= 1e-5
+    assert float((out - ref).detach().abs().max()) <= 1e-5
     loss.backward()
     gw = m_tok.enc.bert.embeddings.word_embeddings.weight.grad
     assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().max()) > 0
