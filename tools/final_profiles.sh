@@ -19,5 +19,6 @@ rm -f $O/prof_$TAG/kp/kp_kernel_trace.csv
 echo "== kernel point"; cut -c1-700 $O/${TAG}_kernel_point.json
 python3 tools/attn_lab.py > $O/${TAG}_attn_lab_h768.json 2>/dev/null || true
 python3 tools/gemm_lab.py --time-only > $O/${TAG}_gemm_lab_h768.txt 2>&1 || true
+bash tools/attn_pmc.sh $O/${TAG}_attn_pmc.json > $O/${TAG}_attn_pmc.log 2>&1 || true
 rm -rf $O/prof_$TAG
 echo "== done"
