@@ -1258,15 +1258,17 @@ extern "C" int bpm_split_rows(const bpm_split_problem* q, int n, void* stream) {
 // ---------------------------------------------------------------------------
 struct ExpP { const void* q; const void* dO; void* qexp; void* dOexp; const void* Pd; float* dbias; int B, H, T, S, dh, dhp, ld; };
 
+constexpr int EXP_NT = 1024;      // 16 waves, one row each per pass (T*B = 16 rows at the headline: one pass)
+
 template <typename CT>
-__global__ __launch_bounds__(NT) void expand_heads_kernel(const Grp<ExpP> grp) {
-    __shared__ float red[NT / 64][128];
+__global__ __launch_bounds__(EXP_NT) void expand_heads_kernel(const Grp<ExpP> grp) {
+    __shared__ float red[EXP_NT / 64][128];
     unsigned bid = blockIdx.x, nblk;
     const ExpP& P = pick(grp, bid, nblk);
     const int h = (int)bid, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c0 = h * P.dh;
     float acc0 = 0.f, acc1 = 0.f;                         // bias sums of columns lane, lane + 64 of this head
-    for (int tb = wv; tb < P.T * P.B; tb += NT / 64) {
+    for (int tb = wv; tb < P.T * P.B; tb += EXP_NT / 64) {
         const int t = tb / P.B, b = tb - t * P.B;
         const size_t r = (size_t)(h * P.T + t) * P.B + b;
         const CT* qrow = (const CT*)P.q + ((size_t)(b * P.H + h) * P.T + t) * P.dhp;
@@ -1288,10 +1290,10 @@ __global__ __launch_bounds__(NT) void expand_heads_kernel(const Grp<ExpP> grp) {
     if (!P.dbias) return;                                 // uniform per block
     red[wv][lane] = acc0; red[wv][lane + 64] = acc1;
     __syncthreads();
-    for (int j = threadIdx.x; j < P.dh; j += NT) {
+    for (int j = threadIdx.x; j < P.dh; j += EXP_NT) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) s += red[w][j];
+        for (int w = 0; w < EXP_NT / 64; ++w) s += red[w][j];
         P.dbias[c0 + j] = s;
     }
 }
@@ -1310,8 +1312,8 @@ extern "C" int bpm_expand_heads(int dtype, const bpm_expand_problem* q, int n, v
         p.B = s.B; p.H = s.H; p.T = s.T; p.S = s.S; p.dh = s.dh; p.dhp = s.dhp; p.ld = s.ld;
         g.blk0[i + 1] = g.blk0[i] + (unsigned)s.H;
     }
-    if (dtype == BPM_BF16) hipLaunchKernelGGL(expand_heads_kernel<bf16_t>, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(expand_heads_kernel<float>, dim3(g.blk0[n]), dim3(NT), 0, (hipStream_t)stream, g);
+    if (dtype == BPM_BF16) hipLaunchKernelGGL(expand_heads_kernel<bf16_t>, dim3(g.blk0[n]), dim3(EXP_NT), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(expand_heads_kernel<float>, dim3(g.blk0[n]), dim3(EXP_NT), 0, (hipStream_t)stream, g);
     BPM_CHECK_LAUNCH();
     return 0;
 }
