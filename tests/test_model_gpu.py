@@ -347,6 +347,58 @@ def test_fused_adam_kernel_exact():
         assert d <= 2e-6, (it, d)
 
 
+@pytest.mark.parametrize("prec,B", [("f32", 3), ("bf16", 2), ("bf16x3", 2)])
+def test_low_rank_key_side_equals_the_dk_dv_route(prec, B):
+    """Level 2 of the pruned 3-modal model, TRAINING mode with every dropout on (attention dropout included: the folded
+    value-bias gradient then carries rowsum(Pd) != 1): the low-rank key side (dS / Pd from the dQ pass, bpm_expand_heads,
+    batched products; engine.EncoderGroupPlan._lowrank) against the dK / dV route on the same weights, inputs and seeds --
+    the same dropout masks, so the two may differ by rounding only.  Key lengths that are not whole 64-key tiles (96)."""
+    import copy
+    from bpmult_amd import engine
+    torch.manual_seed(5)
+    a = args_for("mmtrvat", hidden_sz=48, num_heads=4, layers=3, orig_d_l=32, num_vectors_l=96, num_vectors_a=96,
+                 num_vectors_v=96, attn_dropout=0.2, attn_dropout_a=0.1, attn_dropout_v=0.15)
+    xs = [torch.randn(B, 40, 32), torch.randn(B, 96, 35), torch.randn(B, 77, 74)]
+    m1 = get_model(a)
+    with torch.no_grad():
+        for p in m1.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    m2 = copy.deepcopy(m1)
+    tgt = (torch.randn(B, a.n_classes) > 0).float().cuda()
+    outs = []
+    keep = engine._LOWRANK
+    try:
+        for m, lowrank in ((m1, False), (m2, True)):
+            engine._LOWRANK = lowrank                    # read when the trunk's launch tables are built (first forward)
+            m.precision = prec
+            m = m.cuda().train()
+            m.set_prune_unused_rows(True)
+            x = [t.clone().cuda().requires_grad_(True) for t in xs]
+            logits, z = m(x[0], None, None, *x[1:], output_gate=True)
+            assert m._trunks[B].plan2._lowrank == lowrank and not m._trunks[B].plan1._lowrank
+            torch.nn.functional.binary_cross_entropy_with_logits(logits, tgt).backward()
+            outs.append((logits.detach(), z.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
+                         [t.grad.detach().clone() for t in x]))
+    finally:
+        engine._LOWRANK = keep
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "forward is the same launch sequence"
+    tol_g = {"f32": 5e-6, "bf16x3": 5e-6, "bf16": 1.5e-2}[prec]      # measured 5.7e-7 / 5.2e-7 / 4.5e-3 (profiles/r04_parity_errors.json)
+    rel = lambda u, v: float((u.double() - v.double()).norm() / max(float(v.double().norm()), 1e-12))
+    worst = ("", 0.0)
+    for k in outs[0][2]:
+        g0, g1 = outs[0][2][k], outs[1][2][k]
+        if float(g0.norm()) < 1e-9:                      # (the key-projection bias: rounding noise on one route, zero on the other)
+            assert float(g1.norm()) < 1e-6, k
+            continue
+        r = rel(g1, g0)
+        worst = max(worst, (k, r), key=lambda t: t[1])
+        assert r <= tol_g, (k, r)
+    for g0, g1 in zip(outs[0][3], outs[1][3]):
+        assert rel(g1, g0) <= tol_g
+    _record("lowrank_vs_dkdv/", prec, {"worst_gradient": worst[0], "rel_l2": worst[1]})
+
+
 @pytest.mark.parametrize("model", ["mmtrvat", "mmtrvapt", "mmtrvapt_1layer"])
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_pruned_schedule_equals_dense_schedule(prec, model):
