@@ -48,12 +48,28 @@ __global__ __launch_bounds__(TNT) void tail_linear_kernel(const LinGrp g) {
         float acc[BC];
 #pragma unroll
         for (int r = 0; r < BC; ++r) acc[r] = 0.f;
-        for (int k = lane; k < P.K; k += 64) {
-            const float wv = w[k];
+        // (four k per lane and three such steps in flight where rows are 16-byte aligned: the one-k loop made a K = 2304
+        // column 36 dependent rounds of loads -- 54 us for the first linear layer of the head at hidden 768)
+        const bool wide4 = ((P.K | P.ldw | P.ldin) & 3) == 0 && ((((uintptr_t)P.W | (uintptr_t)P.in) & 15) == 0);
+        if (wide4) {
+#pragma unroll 3
+            for (int k = 4 * lane; k < P.K; k += 256) {
+                const f32x4 wv = *(const f32x4*)(w + k);
 #pragma unroll
-            for (int r = 0; r < BC; ++r) {
-                const int b = min(b0 + r, g.B - 1);
-                acc[r] = fmaf(wv, P.in[(size_t)b * P.ldin + k], acc[r]);
+                for (int r = 0; r < BC; ++r) {
+                    const int b = min(b0 + r, g.B - 1);
+                    const f32x4 xv = *(const f32x4*)(P.in + (size_t)b * P.ldin + k);
+                    acc[r] += (wv[0] * xv[0] + wv[1] * xv[1]) + (wv[2] * xv[2] + wv[3] * xv[3]);
+                }
+            }
+        } else {
+            for (int k = lane; k < P.K; k += 64) {
+                const float wv = w[k];
+#pragma unroll
+                for (int r = 0; r < BC; ++r) {
+                    const int b = min(b0 + r, g.B - 1);
+                    acc[r] = fmaf(wv, P.in[(size_t)b * P.ldin + k], acc[r]);
+                }
             }
         }
 #pragma unroll
@@ -118,7 +134,8 @@ __global__ __launch_bounds__(64 * NN_JG) void tail_nn_kernel(const NnGrp g) {
         if (bid >= g.p[i].blk0) pi = i;
     const NnP& P = g.p[pi];
     bid -= P.blk0;
-    const int col = threadIdx.x & 63, jg = threadIdx.x >> 6;
+    const int col = threadIdx.x & 63;
+    const int jg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the dy reads below become scalar loads
     const int k = bid * 64 + col;
     const bool kok = k < P.K;
     for (int b0 = 0; b0 < g.B; b0 += BC) {
@@ -126,7 +143,7 @@ __global__ __launch_bounds__(64 * NN_JG) void tail_nn_kernel(const NnGrp g) {
 #pragma unroll
         for (int r = 0; r < BC; ++r) acc[r] = 0.f;
         if (kok) {
-#pragma unroll 4
+#pragma unroll 8         // (dy through scalar loads; 4 -> 8 rows in flight per lane changed nothing: 19-22 us per J = 768 product either way)
             for (int j = jg; j < P.J; j += NN_JG) {
                 const float wv = P.W[(size_t)j * P.ldw + k];
 #pragma unroll
