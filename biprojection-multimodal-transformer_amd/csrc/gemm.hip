@@ -1003,6 +1003,18 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
         // weight gradients: one 256 x 256 tile per CU only pays when most CUs get one (measured, 768 x 768 x 4096 problems
         // with bias column sums: 24 problems = 216 tiles 227 -> 181 us, 18 = 162 tiles 169 -> 156, 12 = 108 tiles 114 -> ~150)
         if (variant == BPM_GEMM_TN && tiles_tn * 8 < num_cus() * 5 && !x3) big = false;
+        // products whose columns fill 128-wide tiles but not 256-wide ones (hidden 300: 300 / 384 against 300 / 512): the
+        // two-resident 256 x 128 configuration instead of the 128 x 64 kernel (lab switch BPMULT_NARROW_DMA=0)
+        static const bool narrow_ok = !(std::getenv("BPMULT_NARROW_DMA") && std::atoi(std::getenv("BPMULT_NARROW_DMA")) == 0);
+        bool narrow = narrow_ok && legal && !big && !x3 && variant != BPM_GEMM_TN;
+        long tiles_narrow = 0;
+        for (int i = 0; i < nprob && narrow; ++i) {
+            const bpm_gemm_problem& q = probs[i];
+            const long tm = (q.M + 255) / 256, tn = (q.N + 127) / 128;
+            narrow = q.M >= 256 && q.N >= 128 && q.K >= 256 && (double)q.M * q.N >= 0.75 * (double)(tm * 256) * (double)(tn * 128);
+            tiles_narrow += tm * tn;
+        }
+        narrow = narrow && tiles_narrow >= num_cus();
         if (x3 && !legal) return BPM_ERR_ARG;
         if (x3) big = true;                       // the caller (ops.gemm_grouped) sends what bpm_gemm_x3_eligible accepted
         if (legal && g_force_dma >= 0 && !x3) dma = g_force_dma == CFG_TALL && variant == BPM_GEMM_TN ? -1 : g_force_dma;
@@ -1051,7 +1063,7 @@ extern "C" int bpm_gemm_grouped(int dtype, int variant, const bpm_gemm_problem* 
                 if (r320 * 320 * 21 < r256 * 256 * 20) dma = CFG_TALL;
             }
             if (two_tn || two_kv) dma = CFG_TWO;
-        }
+        } else if (narrow) dma = CFG_TWO;
     }
     // at most 16 rows per problem (level-2 query side under dead-row elimination): the skinny kernel (see there)
     bool skinny = dma < 0 && !x3 && variant != BPM_GEMM_TN && fast;

@@ -1221,6 +1221,48 @@ def test_gemm_skinny_rows(dtype, variant, M, N, K):
         close(heads[..., :N // 12], want, 2 * t, "head-major")
 
 
+@pytest.mark.parametrize("variant,N,K", [(GEMM_NT, 300, 300), (GEMM_NT, 300, 1200), (GEMM_NN, 300, 1200), (GEMM_NN, 300, 300)])
+def test_gemm_hidden_300_products_take_the_two_resident_tiles(variant, N, K):
+    """Hidden 300: 300 columns fill 78 % of 128-wide tiles but 59 % of 256-wide ones -- such launches go to the LDS-DMA
+    kernel's 256 x 128 configuration instead of the 128 x 64 kernel (the dispatcher's `narrow` rule; BASELINE configs[1] /
+    configs[3]: 8.97 -> 8.79 and 56.8 -> 50.6 ms per step).  Six problems of 4000 rows with the encoder's epilogues against
+    fp64, and the launch profiler's tally says which kernel ran."""
+    import ctypes as C
+    from bpmult_amd import _lib
+    M, G = 4000, 6
+    ld = lambda n: pad32(n)
+    ps, checks = [], []
+    for gi in range(G):
+        A, Ar = to_ct(rnd(M, K, seed=60 + gi), BPM_BF16, ld(K))
+        if variant == GEMM_NT:
+            Bm, Br = to_ct(rnd(N, K, seed=70 + gi, scale=K ** -0.5), BPM_BF16, ld(K))
+            ref = Ar.double() @ Br.double().T
+        else:
+            Bm, Br = to_ct(rnd(K, N, seed=70 + gi, scale=K ** -0.5), BPM_BF16, ld(N))
+            ref = Ar.double() @ Br.double()
+        bias, resid = rnd(N, seed=80 + gi).to(DEV), rnd(M, N, seed=90 + gi).to(DEV)
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ps.append(ops.gemm_problem(A, Bm, out, M, N, K, A.shape[1], Bm.shape[1], N, bias_n=bias, resid=resid, ldr=N, flags=ops.F_KPAD))
+        checks.append((out, ref + bias.cpu().double() + resid.cpu().double(), A, Bm, bias, resid))   # (the problems hold raw pointers)
+    L = _lib.lib()
+    kinds = _lib.PROF_KINDS
+    _lib.prof_enable(sum(1 << k for k in kinds.values()))
+    try:
+        ops.gemm_grouped(BPM_BF16, variant, ps)
+        torch.cuda.synchronize()
+        n = {}
+        for name, k in kinds.items():
+            ms, work, cnt = C.c_double(), C.c_double(), C.c_int()
+            _lib.check(L.bpm_prof_collect(k, C.byref(ms), C.byref(work), C.byref(cnt)), "bpm_prof_collect")
+            n[name] = cnt.value
+    finally:
+        _lib.prof_enable(0)
+    dma = "gemm_dma_nt" if variant == GEMM_NT else "gemm_dma_nn"
+    assert n[dma] == 1 and n["gemm_nt"] == 0 and n["gemm_nn"] == 0, n
+    for gi, chk in enumerate(checks):
+        close(chk[0], chk[1], 4e-3, f"problem {gi}")
+
+
 @pytest.mark.parametrize("variant,M,N,K", [(GEMM_NT, 1000, 520, 328), (GEMM_NN, 1000, 520, 328), (GEMM_TN, 520, 1000, 1300),
                                           (GEMM_NT, 4096, 768, 768), (GEMM_TN, 768, 3072, 4096)])
 def test_gemm_two_resident_config(variant, M, N, K):
