@@ -420,9 +420,11 @@ class GroupCfg:
 
 SIDE, JOIN, MARK, WAIT, SIDE2 = "side", "join", "mark", "wait", "side2"
 _SIDE = os.environ.get("BPMULT_SIDE", "1") != "0"
-# dK/dV attention pass: "0" main stream, "1" side stream, "2" a third stream, "auto": side stream at hidden >= 512.
-# dK / dV feed only side-stream work (weight gradients, key/value dgrad).  At hidden 300 the side stream is the longer
-# one and moving the pass there costs 1 ms/step; at hidden 768 the main stream is (41 ms against 23) and it saves ~4.
+# dK/dV attention pass: "0" main stream, "1" side stream, "2" a third stream, "auto": side stream.
+# dK / dV feed only side-stream work (weight gradients, key/value dgrad).  At hidden 768 the main stream is the longer one
+# (41 ms against 23 in round 2) and the pass on the side stream saved ~4 ms.  At hidden 300 the side stream used to be the
+# longer one (round 2: +1 ms/step with the pass there); since the dead-row schedule and the LDS-DMA kernel for its NT / NN
+# products the main stream is (46 against 31 ms busy at batch 64): configs[1] 8.77 -> 8.60, configs[3] 50.1 -> 49.7 ms.
 _DKV_SIDE_ENV = os.environ.get("BPMULT_DKV_SIDE", "auto")
 _side_streams: Dict[Tuple[int, int, bool], "torch.cuda.Stream"] = {}
 # Priority of the side stream: "low" (the dispatcher fills CUs from the main stream first), "normal", or "auto": low
@@ -613,7 +615,7 @@ class EncoderGroupPlan:
                 blk += (2 * d + 15) // 16
                 ud.append(u)
             self._unfold.append((ops.device_table(ud), len(ud), blk))
-        self._dkv_side = _DKV_SIDE_ENV if _DKV_SIDE_ENV != "auto" else ("1" if d >= 512 else "0")
+        self._dkv_side = _DKV_SIDE_ENV if _DKV_SIDE_ENV != "auto" else "1"
         # a group whose query side is a handful of rows (level 2 under dead-row elimination) is bound by its SIDE stream
         # (key / value projections, their weight gradients): its dK / dV pass goes back to the main stream, which idles
         if _DKV_SIDE_ENV == "auto" and max(e.T for e in self.encs) * B <= 64:
