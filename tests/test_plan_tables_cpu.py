@@ -83,3 +83,47 @@ def test_launch_tables_build_from_host_tensors(dry_run, model, kw, prune):
     big = sum(st.params[n].numel() for n in st._store_written)
     assert big > 0.5 * sum(p.numel() for p in st.params.values())
     assert all(n in st.params for n in st._store_written)
+
+
+def test_low_rank_key_side_tables(dry_run):
+    """Level 2 of the pruned 3-modal model (two query rows): its backward table has no dK / dV pass; per layer the dQ pass
+    exports dS / Pd in the [h*T + t][b][padded keys] layout, bpm_expand_heads and ONE NN launch (Qexp W' products + the
+    per-batch-element products as BATCHED problems) follow, and the key / value-source gradient is one batched TN product
+    over K = layers * H * T at the end (engine.EncoderGroupPlan._lowrank)."""
+    from bpmult_amd._lib import F_BATCHED, F_CT_NARROW, GEMM_NN
+    m = get_model(_args("mmtrvat", prune_unused_rows=True))
+    m._ensure_store()
+    B = 2
+    trunk = m._trunk_for(B)
+    p1, p2 = trunk.plan1, trunk.plan2
+    assert p2._lowrank and not p1._lowrank
+    H, L, d, ld = p2.cfg.H, p2.cfg.layers, p2.cfg.d, p2.ld
+    G = len(p2.encs)
+    un = lambda s: s[1] if isinstance(s, tuple) and s[0] in (engine.SIDE, engine.SIDE2) else s
+    steps = [un(s) for s in p2._bwd[(True, True)] if s is not engine.JOIN]
+    fns = [s[0] for s in steps if isinstance(s, tuple) and callable(s[0])]
+    assert ops.attn_bwd_dkv not in fns and fns.count(ops.expand_heads) == L and fns.count(ops.attn_bwd_dq) == L
+    assert ops.attn_bwd_dkv in [un(s)[0] for s in p1._bwd[(True, True)] if s is not engine.JOIN and callable(un(s)[0])]
+    for s in steps:
+        if not (isinstance(s, tuple) and callable(s[0])):
+            continue
+        if s[0] is ops.attn_bwd_dq:
+            for e, b, a in zip(p2.encs, p2.buf, s[2]):
+                Sp = b["Sp"]
+                assert a.dS and a.Pd and (a.xs_b, a.xs_h, a.xs_q) == (Sp, e.T * B * Sp, B * Sp) and Sp % 64 == 0 and Sp >= e.S
+        if s[0] is ops.expand_heads:
+            assert len(s[2]) == G and all(x.B == B and x.H == H and x.T == e.T and x.ld == ld and x.dbias for x, e in zip(s[2], p2.encs))
+        if s[0] is ops.gemm_grouped and s[2] == GEMM_NN and any(q.flags & F_BATCHED for q in s[3]):
+            plain = [q for q in s[3] if not q.flags & F_BATCHED]
+            bat = [q for q in s[3] if q.flags & F_BATCHED]
+            assert len(plain) == 2 * G and len(bat) == 2 * G          # Qexp W_k', dOexp W_v'  |  dS khat, Pd vhat
+            for q, e in zip(bat[::2], p2.encs):
+                Sp = p2.buf[p2.encs.index(e)]["Sp"]
+                assert (q.M, q.N, q.K) == (H * e.T, d, e.S) and q.batch == B and q.flags & F_CT_NARROW
+                assert (q.lda, q.ldb, q.ldc) == (B * Sp, B * ld, B * ld) and (q.batch_stride_a, q.batch_stride_b, q.batch_stride_c) == (Sp, ld, ld)
+            for q, e in zip(plain[::2], p2.encs):
+                assert (q.M, q.N, q.K) == (H * e.T * B, d, d)
+    last_tn = [s for s in steps if isinstance(s, tuple) and s[0] is ops.gemm_grouped and s[2] == GEMM_TN][-1]
+    assert len(last_tn[3]) == 2 * G
+    for q, e in zip(last_tn[3][::2], p2.encs):
+        assert q.flags & F_BATCHED and q.batch == B and (q.M, q.N, q.K) == (e.S, d, L * H * e.T) and q.ldc == B * d and q.batch_stride_c == d
