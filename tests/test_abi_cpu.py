@@ -59,6 +59,19 @@ def test_ctypes_structs_mirror_the_header(cname, cls):
     assert _c_fields(cname) == [f[0] for f in cls._fields_]
 
 
+def test_integration_example_binds_the_current_abi():
+    """INTEGRATION.md's ctypes example (what a maintainer of the reference would copy) lists exactly the fields of
+    bpm_attn_problem, in order, and names the current BPM_ABI_VERSION -- a shorter struct would make the library read the
+    optional dS / Pd pointers past the caller's allocation."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class AttnProblem(C.Structure)"):]
+    block = block[:block.index("lib.bpm_attn_fwd.argtypes")]
+    names = re.findall(r'\("(\w+)", C\.c_', block)
+    assert names == [n for n, _ in _lib.AttnProblem._fields_], names
+    ver = int(re.search(r"#define BPM_ABI_VERSION (\d+)", HEADER).group(1))
+    assert f"bpm_version() == {ver}" in block and f"`BPM_ABI_VERSION` is {ver}" in doc
+
+
 def test_error_strings_and_argument_validation(lib):
     assert lib.bpm_error_string(0) == b"ok"
     assert b"invalid argument" in lib.bpm_error_string(-1)
